@@ -1,0 +1,623 @@
+// Implicit-GEMM convolution family on the fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// All six TensorFlow conv passes the reference's ops.py needs, plus the three
+// matmul passes of ops.linear, reduce to three contraction shapes over the
+// geometry {big image, small image, filter [kh][kw][cb][cs]}:
+//
+//   FPROP  out_small[p, n]   = sum_{tap,c} big[p*s + tap - pad, c] * w[tap][c][n]
+//          (conv2d forward, conv2d_transpose dgrad, linear forward)
+//   TPROP  out_big[q, n]     = sum_{tap,c} small[(q + pad - tap)/s, c] * w[tap][n][c]
+//          (conv2d dgrad, conv2d_transpose forward, linear dgrad); for stride 2 the
+//          output pixels are split into s*s parity classes, each a dense stride-1 problem
+//   WGRAD  dw[tap][cb][cs]   = sum_p big[p*s + tap - pad, cb] * small[p, cs]
+//          (conv2d wgrad, conv2d_transpose wgrad, linear wgrad)
+//
+// One kernel template serves the three: a 256-thread block (4 waves) owns a BM x BN
+// output tile, stages BK=16-deep operand slices through LDS as [k][m] / [k][n] images
+// (double buffered, global loads for slice t+1 in flight while slice t is multiplied),
+// and each wave accumulates TM x TN 32x32 MFMA tiles.  K can be split over blockIdx.z;
+// partial tiles then go to output-shaped slabs that a second kernel sums in fixed order
+// (deterministic, no float atomics).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace gan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_FPROP = 0, MODE_TPROP = 1, MODE_WGRAD = 2 };
+constexpr int BK = 16;
+constexpr int kMaxClasses = 4;
+
+struct ClassInfo {
+    int ph, pw;    // (q + pad) mod stride of this class's output pixels
+    int khc, kwc;  // taps of this class per axis
+    int hq0, wq0;  // first quotient index whose pixel is inside the image
+    int hq, wq;    // quotient extents
+    int M, K;
+};
+
+struct IgemmArgs {
+    gan_conv_geom g;
+    const float* a;
+    const float* b;
+    float* out;
+    const float* bias;
+    int M, N, K;  // FPROP / WGRAD problem; TPROP uses cls[].M / cls[].K and N = g.cb
+    int splits, kt_per_split;
+    long slab_elems;
+    int accumulate;
+    int ncls;
+    ClassInfo cls[kMaxClasses];
+};
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    using T = float4;
+};
+template <>
+struct Vec<1> {
+    using T = float;
+};
+
+template <int V>
+__device__ __forceinline__ void load_vec(float (&dst)[V], const float* p, bool ok) {
+    if constexpr (V == 4) {
+        float4 v = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else {
+        dst[0] = ok ? *p : 0.f;
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, int VA, int VB>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+    static_assert(WM * WN == 4, "four waves per block");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+    constexpr bool A_TRANS = (MODE != MODE_WGRAD);  // A source contiguous along k
+    constexpr bool B_TRANS = (MODE == MODE_TPROP);  // B source contiguous along k
+    // [k][m] images.  A transposing fill writes one dword per lane down a column: a leading
+    // dimension = 2 mod 8 spreads the 4 k-chunks of a row over distinct banks.  A direct fill
+    // writes 16-byte vectors along the row and only needs 16-byte row alignment.
+    constexpr int LDA = BM + (A_TRANS ? 2 : 4);
+    constexpr int LDB = BN + (B_TRANS ? 2 : 4);
+    constexpr int STAGE = BK * (LDA + LDB);
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int split = blockIdx.z % p.splits;
+    const int ci = blockIdx.z / p.splits;
+    const gan_conv_geom& g = p.g;
+
+    int M, N, K;
+    ClassInfo cl = p.cls[0];
+    if constexpr (MODE == MODE_TPROP) {
+        // static selects: a runtime index into the by-value argument would spill it to scratch
+        if (ci == 1) cl = p.cls[1];
+        else if (ci == 2) cl = p.cls[2];
+        else if (ci == 3) cl = p.cls[3];
+        M = cl.M; K = cl.K; N = g.cb;
+    } else {
+        M = p.M; N = p.N; K = p.K;
+    }
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;  // block-uniform: smaller parity classes have fewer row tiles
+    const int n0 = blockIdx.y * BN;
+    const int nkt = (K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nkt, kt0 + p.kt_per_split);
+
+    // ---------------------------------------------------------------- A loader set-up
+    constexpr int A_CPR = A_TRANS ? BK / VA : BM / VA;  // chunks per tile row (k-row for direct)
+    constexpr int A_STEP = 256 / A_CPR;                 // tile rows covered per pass
+    constexpr int A_EXT = A_TRANS ? BM : BK;            // tile rows to cover
+    constexpr int A_PASS = (A_EXT + A_STEP - 1) / A_STEP;
+    const int a_chunk = tid % A_CPR, a_r = tid / A_CPR;
+    // gather source (FPROP: big image; TPROP: small image; WGRAD: big image)
+    const int SH = (MODE == MODE_TPROP) ? g.hs : g.hb;
+    const int SW = (MODE == MODE_TPROP) ? g.ws : g.wb;
+    const int SC = (MODE == MODE_TPROP) ? g.cs : g.cb;
+    const int TW = (MODE == MODE_TPROP) ? cl.kwc : g.kw;  // taps per filter row in the k decode
+
+    int a_base[A_PASS], a_y0[A_PASS], a_x0[A_PASS];  // A_TRANS: per output-pixel row
+    int a_kh = 0, a_kw = 0, a_c = 0;                 // WGRAD: this thread's (tap, channel)
+    bool a_mvalid = true;
+    if constexpr (A_TRANS) {
+        const int row_w = (MODE == MODE_TPROP) ? cl.wq : g.ws;
+        const int row_hw = (MODE == MODE_TPROP) ? cl.hq * cl.wq : g.hs * g.ws;
+#pragma unroll
+        for (int ps = 0; ps < A_PASS; ++ps) {
+            const int m = m0 + a_r + ps * A_STEP;
+            const bool ok = (a_r + ps * A_STEP < BM) && (m < M);
+            const unsigned um = ok ? (unsigned)m : 0u;
+            const int img = um / (unsigned)row_hw;
+            const int rem = um - img * row_hw;
+            const int y = rem / row_w, x = rem - y * row_w;
+            a_base[ps] = ok ? img * SH * SW : -1;
+            if constexpr (MODE == MODE_TPROP) {
+                a_y0[ps] = cl.hq0 + y;
+                a_x0[ps] = cl.wq0 + x;
+            } else {
+                a_y0[ps] = y * g.sh - g.pt;
+                a_x0[ps] = x * g.sw - g.pl;
+            }
+        }
+    } else {
+        const int m = m0 + a_chunk * VA;
+        a_mvalid = m < M;
+        const unsigned um = a_mvalid ? (unsigned)m : 0u;
+        const int tap = um / (unsigned)g.cb;
+        a_c = um - tap * g.cb;
+        a_kh = tap / g.kw;
+        a_kw = tap - a_kh * g.kw;
+    }
+
+    // ---------------------------------------------------------------- B loader set-up
+    constexpr int B_CPR = B_TRANS ? BK / VB : BN / VB;
+    constexpr int B_STEP = 256 / B_CPR;
+    constexpr int B_EXT = B_TRANS ? BN : BK;
+    constexpr int B_PASS = (B_EXT + B_STEP - 1) / B_STEP;
+    const int b_chunk = tid % B_CPR, b_r = tid / B_CPR;
+
+    float a_reg[A_PASS][VA], b_reg[B_PASS][VB];
+
+    auto load_a = [&](int kt) {
+        if constexpr (A_TRANS) {
+            const int k = kt * BK + a_chunk * VA;
+            const bool kv = k < K;
+            const unsigned uk = kv ? (unsigned)k : 0u;
+            const int tapc = uk / (unsigned)SC;
+            const int cc = uk - tapc * SC;
+            const int ta = tapc / TW, tb = tapc - ta * TW;
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
+                const int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                const bool ok = kv && a_base[ps] >= 0 && (unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW;
+                const long off = ((long)(a_base[ps] + iy * SW + ix)) * SC + cc;
+                load_vec<VA>(a_reg[ps], p.a + (ok ? off : 0), ok);
+            }
+        } else {
+            const int hw = g.hs * g.ws;
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const int kr = a_r + ps * A_STEP;
+                const int k = kt * BK + kr;
+                const bool kv = (kr < BK) && (k < K) && a_mvalid;
+                const unsigned uk = kv ? (unsigned)k : 0u;
+                const int img = uk / (unsigned)hw;
+                const int rem = uk - img * hw;
+                const int oy = rem / g.ws, ox = rem - oy * g.ws;
+                const int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
+                const bool ok = kv && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
+                const long off = ((long)((img * g.hb + iy) * g.wb + ix)) * g.cb + a_c;
+                load_vec<VA>(a_reg[ps], p.a + (ok ? off : 0), ok);
+            }
+        }
+    };
+
+    auto load_b = [&](int kt) {
+        if constexpr (B_TRANS) {
+            // w[tap][n][c]: contiguous along k = (class tap, c)
+            const int k = kt * BK + b_chunk * VB;
+            const bool kv = k < K;
+            const unsigned uk = kv ? (unsigned)k : 0u;
+            const int tapc = uk / (unsigned)g.cs;
+            const int cc = uk - tapc * g.cs;
+            const int ta = tapc / cl.kwc, tb = tapc - ta * cl.kwc;
+            const int wtap = (cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb);
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const int nr = b_r + ps * B_STEP;
+                const int n = n0 + nr;
+                const bool ok = kv && (nr < BN) && (n < N);
+                const long off = ((long)(wtap * g.cb + n)) * g.cs + cc;
+                load_vec<VB>(b_reg[ps], p.b + (ok ? off : 0), ok);
+            }
+        } else {
+            // row-major [K][N] (filter as [taps*cb][cs], or the small image as [pixels][cs])
+            const int n = n0 + b_chunk * VB;
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const int kr = b_r + ps * B_STEP;
+                const int k = kt * BK + kr;
+                const bool ok = (kr < BK) && (k < K) && (n < N);
+                const long off = (long)k * N + n;
+                load_vec<VB>(b_reg[ps], p.b + (ok ? off : 0), ok);
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + BK * LDA;
+        if constexpr (A_TRANS) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const int r = a_r + ps * A_STEP;
+                if (r < BM) {
+#pragma unroll
+                    for (int v = 0; v < VA; ++v) As[(a_chunk * VA + v) * LDA + r] = a_reg[ps][v];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const int kr = a_r + ps * A_STEP;
+                if (kr < BK) {
+                    if constexpr (VA == 4) {
+                        *reinterpret_cast<float4*>(&As[kr * LDA + a_chunk * 4]) =
+                            make_float4(a_reg[ps][0], a_reg[ps][1], a_reg[ps][2], a_reg[ps][3]);
+                    } else {
+                        As[kr * LDA + a_chunk] = a_reg[ps][0];
+                    }
+                }
+            }
+        }
+        if constexpr (B_TRANS) {
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const int r = b_r + ps * B_STEP;
+                if (r < BN) {
+#pragma unroll
+                    for (int v = 0; v < VB; ++v) Bs[(b_chunk * VB + v) * LDB + r] = b_reg[ps][v];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const int kr = b_r + ps * B_STEP;
+                if (kr < BK) {
+                    if constexpr (VB == 4) {
+                        *reinterpret_cast<float4*>(&Bs[kr * LDB + b_chunk * 4]) =
+                            make_float4(b_reg[ps][0], b_reg[ps][1], b_reg[ps][2], b_reg[ps][3]);
+                    } else {
+                        Bs[kr * LDB + b_chunk] = b_reg[ps][0];
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_a = wm * (BM / WM) + (lane & 31);
+    const int frag_b = wn * (BN / WN) + (lane & 31);
+    const int kh2 = lane >> 5;
+
+    if (kt0 < kt1) {
+        load_a(kt0);
+        load_b(kt0);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const bool more = kt + 1 < kt1;
+            if (more) {
+                load_a(kt + 1);
+                load_b(kt + 1);
+            }
+            const float* As = smem + buf * STAGE;
+            const float* Bs = As + BK * LDA;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(kk + kh2) * LDA + frag_a + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + kh2) * LDB + frag_b + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // Row -> output offset table (element offset of channel 0, or -1), built once per block.
+    int* rowoff = reinterpret_cast<int*>(smem);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < M) {
+            if constexpr (MODE == MODE_TPROP) {
+                const int hw = cl.hq * cl.wq;
+                const int img = m / hw;
+                const int rem = m - img * hw;
+                const int yq = rem / cl.wq, xq = rem - yq * cl.wq;
+                const int y = g.sh * (cl.hq0 + yq) + cl.ph - g.pt;
+                const int x = g.sw * (cl.wq0 + xq) + cl.pw - g.pl;
+                off = ((img * g.hb + y) * g.wb + x) * g.cb;
+            } else {
+                off = m * N;
+            }
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+
+    float* dst = p.out + (p.splits > 1 ? (long)split * p.slab_elems : 0L);
+    const bool direct = p.splits == 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            const int off = rowoff[row];
+            if (off < 0) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+                if (n < N) {
+                    float v = acc[i][j][r];
+                    if (direct) {
+                        if (p.bias) v += p.bias[n];
+                        if (p.accumulate) v += dst[off + n];
+                    }
+                    dst[off + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + bias[i % c] + sum_s slab[s][i]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                    const float* __restrict__ bias, long elems, int c, int splits,
+                                    int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    if ((elems & 3) == 0 && (c & 3) == 0) {
+        const long n4 = elems >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 s = reinterpret_cast<const float4*>(slabs)[i];
+            for (int k = 1; k < splits; ++k) {
+                const float4 t = reinterpret_cast<const float4*>(slabs + (long)k * elems)[i];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            if (bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(bias + (int)((i * 4) % c));
+                s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
+            }
+            if (accumulate) {
+                const float4 o = reinterpret_cast<const float4*>(out)[i];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            reinterpret_cast<float4*>(out)[i] = s;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += stride) {
+            float s = slabs[i];
+            for (int k = 1; k < splits; ++k) s += slabs[(long)k * elems + i];
+            if (bias) s += bias[(int)(i % c)];
+            if (accumulate) s += out[i];
+            out[i] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct TileCfg {
+    int bm, bn;
+};
+
+struct Plan {
+    int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
+    int va, vb;
+    int splits, kt_per_split;
+    int mt, nt;
+    long out_elems;
+};
+
+static const TileCfg kCfg[4] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+
+static int geom_check(const gan_conv_geom& g) {
+    GAN_CHECK_ARG(g.n > 0 && g.hb > 0 && g.wb > 0 && g.cb > 0 && g.hs > 0 && g.ws > 0 && g.cs > 0,
+                  "conv geometry: non-positive dimension");
+    GAN_CHECK_ARG(g.kh > 0 && g.kw > 0 && g.kh <= 16 && g.kw <= 16, "conv geometry: filter taps must be in 1..16");
+    GAN_CHECK_ARG((g.sh == 1 || g.sh == 2) && (g.sw == 1 || g.sw == 2), "conv geometry: strides must be 1 or 2");
+    GAN_CHECK_ARG(g.pt >= 0 && g.pl >= 0 && g.pt < g.kh && g.pl < g.kw, "conv geometry: pad_before out of range");
+    // the last filter row/column must not start beyond the padded image
+    GAN_CHECK_ARG((g.hs - 1) * g.sh - g.pt < g.hb && (g.ws - 1) * g.sw - g.pl < g.wb,
+                  "conv geometry: small side too large for big side");
+    const long big = (long)g.n * g.hb * g.wb * g.cb, small = (long)g.n * g.hs * g.ws * g.cs;
+    const long wel = (long)g.kh * g.kw * g.cb * g.cs;
+    GAN_CHECK_ARG(big < (1L << 31) && small < (1L << 31) && wel < (1L << 31),
+                  "conv geometry: tensors of 2^31 elements or more are not supported");
+    return 0;
+}
+
+static void build_classes(const gan_conv_geom& g, IgemmArgs& a) {
+    a.ncls = 0;
+    for (int ph = 0; ph < g.sh; ++ph)
+        for (int pw = 0; pw < g.sw; ++pw) {
+            ClassInfo c;
+            c.ph = ph; c.pw = pw;
+            c.khc = ph < g.kh ? (g.kh - ph + g.sh - 1) / g.sh : 0;
+            c.kwc = pw < g.kw ? (g.kw - pw + g.sw - 1) / g.sw : 0;
+            c.hq0 = g.pt > ph ? (g.pt - ph + g.sh - 1) / g.sh : 0;
+            c.wq0 = g.pl > pw ? (g.pl - pw + g.sw - 1) / g.sw : 0;
+            const int hmax = g.hb - 1 + g.pt - ph, wmax = g.wb - 1 + g.pl - pw;
+            c.hq = hmax >= 0 ? hmax / g.sh - c.hq0 + 1 : 0;
+            c.wq = wmax >= 0 ? wmax / g.sw - c.wq0 + 1 : 0;
+            if (c.hq < 0) c.hq = 0;
+            if (c.wq < 0) c.wq = 0;
+            c.M = g.n * c.hq * c.wq;
+            c.K = c.khc * c.kwc * g.cs;
+            if (c.kwc == 0) c.kwc = 1;  // keeps the k decode's division defined; K is 0 anyway
+            a.cls[a.ncls++] = c;
+        }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+static Plan make_plan(int mode, const IgemmArgs& a) {
+    const gan_conv_geom& g = a.g;
+    Plan pl;
+    int M, N, K;
+    if (mode == MODE_TPROP) {
+        M = 0; K = 0;
+        for (int i = 0; i < a.ncls; ++i) {
+            if (a.cls[i].M > M) M = a.cls[i].M;
+            if (a.cls[i].K > K) K = a.cls[i].K;
+        }
+        N = g.cb;
+        pl.out_elems = (long)g.n * g.hb * g.wb * g.cb;
+        pl.va = pl.vb = (g.cs % 4 == 0) ? 4 : 1;
+    } else {
+        M = a.M; N = a.N; K = a.K;
+        pl.out_elems = (long)M * N;
+        pl.va = (g.cb % 4 == 0) ? 4 : 1;
+        pl.vb = (g.cs % 4 == 0) ? 4 : 1;
+    }
+    if (!aligned16(a.a)) pl.va = 1;
+    if (!aligned16(a.b)) pl.vb = 1;
+    if (N <= 32) pl.cfg = 3;
+    else if (N <= 64) pl.cfg = (M >= 8192) ? 1 : 2;
+    else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
+    if (const char* e = getenv("GAN_HIP_FORCE_CFG")) pl.cfg = atoi(e) & 3;
+    const int bm = kCfg[pl.cfg].bm, bn = kCfg[pl.cfg].bn;
+    pl.mt = (M + bm - 1) / bm;
+    pl.nt = (N + bn - 1) / bn;
+    const int nkt = (K + BK - 1) / BK;
+    const long blocks = (long)pl.mt * pl.nt * (mode == MODE_TPROP ? a.ncls : 1);
+    int splits = 1;
+    const long target = 768;  // ~3 blocks per CU
+    if (blocks < target) {
+        splits = (int)(target / blocks);
+        const int max_by_k = nkt / 8 > 0 ? nkt / 8 : 1;  // keep >= 8 k-slices (128 deep) per split
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    if (const char* e = getenv("GAN_HIP_FORCE_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : 1;
+    pl.kt_per_split = nkt > 0 ? (nkt + splits - 1) / splits : 1;
+    pl.splits = nkt > 0 ? (nkt + pl.kt_per_split - 1) / pl.kt_per_split : 1;
+    if (pl.splits < 1) pl.splits = 1;
+    return pl;
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+static void launch_vec(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_t s) {
+    if (pl.va == 4 && pl.vb == 4)
+        hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, 4, 4>), grid, dim3(256), 0, s, a);
+    else if (pl.va == 1 && pl.vb == 4)
+        hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (pl.va == 4 && pl.vb == 1)
+        hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, 4, 1>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, 1, 1>), grid, dim3(256), 0, s, a);
+}
+
+template <int MODE>
+static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_t s) {
+    switch (pl.cfg) {
+        case 0: launch_vec<MODE, 128, 128, 2, 2>(a, pl, grid, s); break;
+        case 1: launch_vec<MODE, 128, 64, 2, 2>(a, pl, grid, s); break;
+        case 2: launch_vec<MODE, 64, 64, 2, 2>(a, pl, grid, s); break;
+        default: launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break;
+    }
+}
+
+static size_t plan_ws_bytes(const Plan& pl) {
+    return pl.splits > 1 ? (size_t)pl.splits * pl.out_elems * sizeof(float) : 0;
+}
+
+// Runs one contraction.  `out_c` is the channel count of the output's last axis (bias period).
+int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what) {
+    if (mode == MODE_TPROP) build_classes(a.g, a);
+    else a.ncls = 1;
+    Plan pl = make_plan(mode, a);
+    const size_t need = plan_ws_bytes(pl);
+    GAN_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= need), "%s: workspace of %zu bytes needed, %zu given",
+                  what, need, ws_bytes);
+    float* final_out = a.out;
+    const float* bias = a.bias;
+    const int accumulate = a.accumulate;
+    a.splits = pl.splits;
+    a.kt_per_split = pl.kt_per_split;
+    a.slab_elems = pl.out_elems;
+    if (pl.splits > 1) {
+        a.out = static_cast<float*>(ws);
+        a.bias = nullptr;
+        a.accumulate = 0;
+    }
+    dim3 grid(pl.mt, pl.nt, pl.splits * a.ncls);
+    switch (mode) {
+        case MODE_FPROP: launch_cfg<MODE_FPROP>(a, pl, grid, s); break;
+        case MODE_TPROP: launch_cfg<MODE_TPROP>(a, pl, grid, s); break;
+        default: launch_cfg<MODE_WGRAD>(a, pl, grid, s); break;
+    }
+    if (int rc = check_launch(what)) return rc;
+    if (pl.splits > 1) {
+        long work = (pl.out_elems + 3) / 4;
+        int blocks = (int)((work + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(ws),
+                           final_out, bias, pl.out_elems, out_c, pl.splits, accumulate);
+        if (int rc = check_launch(what)) return rc;
+    }
+    return 0;
+}
+
+size_t igemm_ws_bytes(int mode, IgemmArgs a) {
+    if (mode == MODE_TPROP) build_classes(a.g, a);
+    else a.ncls = 1;
+    // alignment of the (unknown) pointers does not change the split plan
+    a.a = a.b = nullptr;
+    return plan_ws_bytes(make_plan(mode, a));
+}
+
+IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out,
+                    const float* bias, int accumulate) {
+    IgemmArgs r;
+    r.g = g;
+    r.a = a; r.b = b; r.out = out; r.bias = bias;
+    r.accumulate = accumulate;
+    r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1;
+    for (int i = 0; i < kMaxClasses; ++i) r.cls[i] = ClassInfo{0, 0, 1, 1, 0, 0, 0, 0, 0, 0};
+    if (mode == MODE_FPROP) {
+        r.M = g.n * g.hs * g.ws; r.N = g.cs; r.K = g.kh * g.kw * g.cb;
+    } else if (mode == MODE_WGRAD) {
+        r.M = g.kh * g.kw * g.cb; r.N = g.cs; r.K = g.n * g.hs * g.ws;
+    } else {
+        r.M = 0; r.N = g.cb; r.K = 0;
+    }
+    return r;
+}
+
+int conv_geom_check(const gan_conv_geom* g) {
+    GAN_CHECK_ARG(g != nullptr, "conv geometry: NULL");
+    return geom_check(*g);
+}
+
+size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g) {
+    return igemm_ws_bytes(mode, make_args(mode, g, nullptr, nullptr, nullptr, nullptr, 0));
+}
+
+int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
+                   int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what) {
+    return run_igemm(mode, make_args(mode, g, a, b, out, bias, accumulate), out_c, ws, ws_bytes, s, what);
+}
+
+}  // namespace gan

@@ -1,0 +1,535 @@
+"""Layer primitives with the reference's `models/ops.py` signatures, backed by libgan_hip.
+
+Drop-in surface (names, positional order and defaults as in the reference, ops.py:30-115):
+    batch_norm(epsilon=1e-5, momentum=0.9, name="batch_norm") / __call__(x, train=True)
+    conv_cond_concat(x, y)
+    conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding='SAME', name="conv2d")
+    deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="deconv2d", with_w=False)
+    lrelu(x, leak=0.2, name="lrelu")
+    linear(input_, output_size, scope_name=None, stddev=0.02, bias_start=0.0, with_w=False, reuse=None)
+    concat(tensors, axis)
+plus what the model files take from TensorFlow directly (relu, tanh, sigmoid, reflect pad, the
+losses) and `instance_norm`, which the reference does not have.
+
+Tensors are dense fp32 NHWC torch tensors in GPU memory.  torch.autograd only sequences the
+backward; every forward and backward computation is a call into the HIP library.  Weight
+gradients are not returned through autograd: the backward of each layer writes them straight into
+the owning optimiser group's gradient arena when that variable is being trained in the current
+update (`Variable.wants_grad`), which is how `minimize(loss, var_list=...)` restricts the work.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from . import variables as V
+from ._lib import ACT_CODES, check, lib, ptr, stream
+
+variable_scope = V.variable_scope
+
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+_token = {}
+
+
+def _grad_token(device):
+    """A leaf that requires grad, threaded through every layer so that the layer's backward runs
+    (and can emit weight gradients) even when its data input needs no gradient."""
+    t = _token.get(device)
+    if t is None:
+        t = torch.zeros(1, device=device, requires_grad=True)
+        _token[device] = t
+    return t
+
+
+def same_pad(in_size, k, s):
+    """TensorFlow 'SAME': out = ceil(in/s), total = max((out-1)*s+k-in, 0), before = total//2."""
+    out = int(math.ceil(float(in_size) / float(s)))
+    total = max((out - 1) * s + k - in_size, 0)
+    return out, total // 2
+
+
+def _conv_geom(n, h, w, c_big, c_small, k_h, k_w, d_h, d_w, padding, small_hw=None):
+    if padding == 'SAME':
+        hs, pt = same_pad(h, k_h, d_h)
+        ws, pl = same_pad(w, k_w, d_w)
+    elif padding == 'VALID':
+        if h < k_h or w < k_w:
+            raise ValueError("VALID convolution: %dx%d filter larger than %dx%d input" % (k_h, k_w, h, w))
+        hs, ws, pt, pl = (h - k_h) // d_h + 1, (w - k_w) // d_w + 1, 0, 0
+    else:
+        raise ValueError("padding must be 'SAME' or 'VALID', got %r" % (padding,))
+    if small_hw is not None and tuple(small_hw) != (hs, ws):
+        raise ValueError("conv2d_transpose: output_shape %s does not match input spatial size %s "
+                         "(a stride-%dx%d SAME conv of the output gives %s)"
+                         % ((h, w), tuple(small_hw), d_h, d_w, (hs, ws)))
+    return _lib.conv_geom(n, h, w, c_big, hs, ws, c_small, k_h, k_w, d_h, d_w, pt, pl)
+
+
+_ws_cache = {}
+
+
+def _conv_ws(g):
+    key = ('c',) + g.key()
+    n = _ws_cache.get(key)
+    if n is None:
+        n = _ws_cache[key] = int(lib.gan_conv_workspace_bytes(ctypes.byref(g)))
+    return _lib.workspace(n)
+
+
+def _lin_ws(rows, i, o):
+    key = ('l', rows, i, o)
+    n = _ws_cache.get(key)
+    if n is None:
+        n = _ws_cache[key] = int(lib.gan_linear_workspace_bytes(rows, i, o))
+    return _lib.workspace(n)
+
+
+def _bn_ws(groups, rows, c):
+    key = ('b', groups, rows, c)
+    n = _ws_cache.get(key)
+    if n is None:
+        n = _ws_cache[key] = int(lib.gan_bn_workspace_bytes(groups, rows, c))
+    return _lib.workspace(n)
+
+
+def _dense(x):
+    if x.dtype != torch.float32:
+        raise TypeError("expected a float32 tensor, got %s" % x.dtype)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# conv2d / deconv2d / linear
+# --------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, w, b, g):
+        x = _dense(x)
+        y = torch.empty((g.n, g.hs, g.ws, g.cs), dtype=torch.float32, device=x.device)
+        wp, wn = _conv_ws(g)
+        check(lib.gan_conv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
+        ctx.save_for_backward(x)
+        ctx.w, ctx.b, ctx.g = w, b, g
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b, g = ctx.w, ctx.b, ctx.g
+        dy = _dense(dy)
+        wp, wn = _conv_ws(g)
+        if w.wants_grad:
+            dw, acc = w.grad_target()
+            db, accb = b.grad_target()
+            assert acc == accb
+            check(lib.gan_conv2d_wgrad(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.gan_conv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
+        return dx, None, None, None, None
+
+
+class _Deconv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, w, b, g):
+        x = _dense(x)
+        y = torch.empty((g.n, g.hb, g.wb, g.cb), dtype=torch.float32, device=x.device)
+        wp, wn = _conv_ws(g)
+        check(lib.gan_deconv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
+        ctx.save_for_backward(x)
+        ctx.w, ctx.b, ctx.g = w, b, g
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b, g = ctx.w, ctx.b, ctx.g
+        dy = _dense(dy)
+        wp, wn = _conv_ws(g)
+        if w.wants_grad:
+            dw, acc = w.grad_target()
+            db, accb = b.grad_target()
+            assert acc == accb
+            check(lib.gan_deconv2d_wgrad(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.gan_deconv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
+        return dx, None, None, None, None
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, m, b):
+        x = _dense(x)
+        rows, i = x.shape
+        o = m.shape[1]
+        y = torch.empty((rows, o), dtype=torch.float32, device=x.device)
+        wp, wn = _lin_ws(rows, i, o)
+        check(lib.gan_linear_fwd(rows, i, o, ptr(x), ptr(m.data), ptr(b.data), ptr(y), wp, wn, stream()))
+        ctx.save_for_backward(x)
+        ctx.m, ctx.b = m, b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        m, b = ctx.m, ctx.b
+        dy = _dense(dy)
+        rows, i = x.shape
+        o = m.shape[1]
+        wp, wn = _lin_ws(rows, i, o)
+        if m.wants_grad:
+            dm, acc = m.grad_target()
+            db, accb = b.grad_target()
+            assert acc == accb
+            check(lib.gan_linear_wgrad(rows, i, o, ptr(x), ptr(dy), ptr(dm), ptr(db), acc, wp, wn, stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.gan_linear_dgrad(rows, i, o, ptr(dy), ptr(m.data), ptr(dx), wp, wn, stream()))
+        return dx, None, None, None
+
+
+def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding='SAME', name="conv2d"):
+    """ops.py:64-74: w [k_h,k_w,Cin,Cout] truncated-normal, biases zeros, tf.nn.conv2d + bias_add."""
+    st = V.default_store()
+    n, h, w_, cin = input_.shape
+    with st.variable_scope(name):
+        w = st.get_variable('w', [k_h, k_w, cin, output_dim], V.truncated_normal_initializer(stddev))
+        biases = st.get_variable('biases', [output_dim], V.constant_initializer(0.0))
+    g = _conv_geom(n, h, w_, cin, output_dim, k_h, k_w, d_h, d_w, padding)
+    return _Conv2dFn.apply(input_, _grad_token(input_.device), w, biases, g)
+
+
+def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="deconv2d", with_w=False):
+    """ops.py:76-99: w [k_h,k_w,Cout,Cin] normal, tf.nn.conv2d_transpose (SAME) + bias_add.
+    `output_shape` carries the static batch size, as in the reference."""
+    st = V.default_store()
+    n, hs, ws, cin = input_.shape
+    on, oh, ow, oc = [int(v) for v in output_shape]
+    if on != n:
+        raise ValueError("deconv2d: output_shape batch %d != input batch %d" % (on, n))
+    with st.variable_scope(name):
+        w = st.get_variable('w', [k_h, k_w, oc, cin], V.random_normal_initializer(stddev))
+        biases = st.get_variable('biases', [oc], V.constant_initializer(0.0))
+    g = _conv_geom(n, oh, ow, oc, cin, k_h, k_w, d_h, d_w, 'SAME', small_hw=(hs, ws))
+    deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device), w, biases, g)
+    if with_w:
+        return deconv, w, biases
+    return deconv
+
+
+def linear(input_, output_size, scope_name=None, stddev=0.02, bias_start=0.0, with_w=False, reuse=None):
+    """ops.py:104-115: Matrix [in,out] normal, bias constant, tf.matmul + bias."""
+    st = V.default_store()
+    if input_.dim() != 2:
+        raise ValueError("linear expects a rank-2 input, got shape %s" % (tuple(input_.shape),))
+    with st.variable_scope(scope_name or "Linear", reuse=reuse):
+        matrix = st.get_variable("Matrix", [input_.shape[1], output_size], V.random_normal_initializer(stddev))
+        bias = st.get_variable("bias", [output_size], V.constant_initializer(bias_start))
+    y = _LinearFn.apply(input_, _grad_token(input_.device), matrix, bias)
+    if with_w:
+        return y, matrix, bias
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# batch norm / instance norm (fused with the activation that follows)
+# --------------------------------------------------------------------------------------------
+class _NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, token, gamma, beta, mm, mv, groups, eps, momentum, unbiased, act, act_param):
+        x = _dense(x)
+        c = x.shape[-1]
+        rows = x.numel() // c // groups
+        y = torch.empty_like(x)
+        save_mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        save_rstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        wp, wn = _bn_ws(groups, rows, c)
+        res = None if residual is None else _dense(residual)
+        check(lib.gan_bn_fwd_train(ptr(x), ptr(gamma.data), ptr(beta.data),
+                                   None if mm is None else ptr(mm.data), None if mv is None else ptr(mv.data),
+                                   ptr(res), ptr(y), ptr(save_mean), ptr(save_rstd), groups, rows, c,
+                                   eps, momentum, int(unbiased), act, act_param, wp, wn, stream()))
+        ctx.save_for_backward(x, save_mean, save_rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.cfg = (groups, rows, c, act, act_param)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, save_mean, save_rstd = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
+        groups, rows, c, act, act_param = ctx.cfg
+        dy = _dense(dy)
+        dg = db = None
+        acc = 0
+        if gamma.wants_grad:
+            dg, acc = gamma.grad_target()
+            db, accb = beta.grad_target()
+            assert acc == accb
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if dx is not None or dg is not None:
+            wp, wn = _bn_ws(groups, rows, c)
+            check(lib.gan_bn_bwd(ptr(x), ptr(gamma.data), ptr(beta.data), ptr(save_mean), ptr(save_rstd), ptr(dy),
+                                 ptr(dx), ptr(dg), ptr(db), acc, groups, rows, c, act, act_param, wp, wn, stream()))
+        dres = dy if ctx.needs_input_grad[1] else None
+        return (dx, dres) + (None,) * 11
+
+
+class batch_norm(object):
+    """ops.py:30-44 (tf.contrib.layers.batch_norm with decay=momentum, updates_collections=None,
+    scale=True).  Variables beta / gamma / moving_mean / moving_variance are created under the
+    CALLER's current scope + name on first use.  Training mode normalises with the biased batch
+    variance and updates the moving averages inside every forward.
+
+    Extensions (keyword-only, default to the reference behaviour): `act` / `act_param` fuse the
+    activation that follows; `residual` is added after it (the ResNet block's `y + x`).
+    `unbiased_moving_var` picks the Bessel-corrected batch variance for the moving average, which is
+    what TensorFlow's fused kernel feeds it (the unfused one feeds the biased value: default)."""
+
+    unbiased_moving_var = False
+
+    def __init__(self, epsilon=1e-5, momentum=0.9, name="batch_norm"):
+        self.epsilon = epsilon
+        self.momentum = momentum
+        self.name = name
+
+    def __call__(self, x, train=True, act=None, act_param=0.2, residual=None):
+        st = V.default_store()
+        c = x.shape[-1]
+        with st.variable_scope(self.name):
+            beta = st.get_variable('beta', [c], V.constant_initializer(0.0))
+            gamma = st.get_variable('gamma', [c], V.constant_initializer(1.0))
+            mm = st.get_variable('moving_mean', [c], V.constant_initializer(0.0), trainable=False)
+            mv = st.get_variable('moving_variance', [c], V.constant_initializer(1.0), trainable=False)
+        code = ACT_CODES[act]
+        if train:
+            return _NormFn.apply(x, residual, _grad_token(x.device), gamma, beta, mm, mv, 1, float(self.epsilon),
+                                 float(self.momentum), self.unbiased_moving_var, code, float(act_param))
+        if residual is not None:
+            raise ValueError("batch_norm(train=False) does not take a residual")
+        x = _dense(x.detach())
+        y = torch.empty_like(x)
+        check(lib.gan_bn_fwd_eval(ptr(x), ptr(gamma.data), ptr(beta.data), ptr(mm.data), ptr(mv.data), ptr(y),
+                                  x.numel() // c, c, float(self.epsilon), code, float(act_param), stream()))
+        return y
+
+
+def instance_norm(x, name="instance_norm", epsilon=1e-5, act=None, act_param=0.2):
+    """Extension: per-sample, per-channel normalisation with learned gamma / beta.  Defined as
+    batch_norm(train=True) applied to each sample on its own; the reference's CycleGAN reaches the
+    same arithmetic through batch_norm at batch size 1 (cyclegan_module.py:16-18, scripts/CycleGAN.sh:2)."""
+    st = V.default_store()
+    if x.dim() != 4:
+        raise ValueError("instance_norm expects NHWC input")
+    c = x.shape[-1]
+    with st.variable_scope(name):
+        beta = st.get_variable('beta', [c], V.constant_initializer(0.0))
+        gamma = st.get_variable('gamma', [c], V.constant_initializer(1.0))
+    return _NormFn.apply(x, None, _grad_token(x.device), gamma, beta, None, None, int(x.shape[0]), float(epsilon),
+                         0.0, False, ACT_CODES[act], float(act_param))
+
+
+# --------------------------------------------------------------------------------------------
+# activations, add, concat, reflect pad
+# --------------------------------------------------------------------------------------------
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, param, scale, shift):
+        x = _dense(x)
+        y = torch.empty_like(x)
+        check(lib.gan_act_fwd(ptr(x), ptr(y), x.numel(), act, param, scale, shift, stream()))
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, param, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, param, scale, shift = ctx.cfg
+        dy = _dense(dy)
+        dx = torch.empty_like(y)
+        check(lib.gan_act_bwd(ptr(y), ptr(dy), ptr(dx), y.numel(), act, param, scale, shift, stream()))
+        return dx, None, None, None, None
+
+
+def lrelu(x, leak=0.2, name="lrelu"):
+    """ops.py:101-102: tf.maximum(x, leak*x)."""
+    return _ActFn.apply(x, _lib.ACT_LRELU, float(leak), 1.0, 0.0)
+
+
+def relu(x):
+    return _ActFn.apply(x, _lib.ACT_RELU, 0.0, 1.0, 0.0)
+
+
+def tanh(x, scale=1.0, shift=0.0):
+    """tf.nn.tanh; scale/shift fold the `tanh(h4)/2. + 0.5` of text2image.py:198 into the same pass."""
+    return _ActFn.apply(x, _lib.ACT_TANH, 0.0, float(scale), float(shift))
+
+
+def sigmoid(x):
+    return _ActFn.apply(x, _lib.ACT_SIGMOID, 0.0, 1.0, 0.0)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _dense(a), _dense(b)
+        y = torch.empty_like(a)
+        check(lib.gan_add_fwd(ptr(a), ptr(b), ptr(y), a.numel(), stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise ValueError("add: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
+    return _AddFn.apply(a, b)
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, rows_per_b):
+        a, b = _dense(a), _dense(b)
+        ca, cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // ca
+        out = torch.empty(tuple(a.shape[:-1]) + (ca + cb,), dtype=torch.float32, device=a.device)
+        check(lib.gan_concat_fwd(ptr(a), ptr(b), ptr(out), rows, ca, cb, rows_per_b, stream()))
+        ctx.cfg = (tuple(a.shape), tuple(b.shape), rows, ca, cb, rows_per_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ashape, bshape, rows, ca, cb, rpb = ctx.cfg
+        dout = _dense(dout)
+        da = torch.empty(ashape, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty(bshape, dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            check(lib.gan_concat_bwd(ptr(dout), ptr(da), ptr(db), rows, ca, cb, rpb, stream()))
+        return da, db, None
+
+
+def concat(tensors, axis, *args, **kwargs):
+    """ops.py:23-28.  Last-axis concatenation (the only kind the hot path uses)."""
+    tensors = list(tensors)
+    nd = tensors[0].dim()
+    if axis not in (nd - 1, -1):
+        raise ValueError("concat: only the last axis is supported (got axis=%d for rank %d)" % (axis, nd))
+    out = tensors[0]
+    for t in tensors[1:]:
+        if tuple(t.shape[:-1]) != tuple(out.shape[:-1]):
+            raise ValueError("concat: leading shapes %s and %s differ" % (tuple(out.shape), tuple(t.shape)))
+        out = _ConcatFn.apply(out, t, 1)
+    return out
+
+
+def conv_cond_concat(x, y):
+    """ops.py:57-62: tile y [N,1,1,Y] over the feature map of x [N,H,W,C] and concat on channels."""
+    n, h, w, _ = x.shape
+    if y.dim() != 4 or y.shape[0] != n or y.shape[1] != 1 or y.shape[2] != 1:
+        raise ValueError("conv_cond_concat: y must be [N,1,1,Y], got %s" % (tuple(y.shape),))
+    return _ConcatFn.apply(x, y, int(h * w))
+
+
+class _ReflectPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _dense(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, h + 2 * p, w + 2 * p, c), dtype=torch.float32, device=x.device)
+        check(lib.gan_reflect_pad_fwd(ptr(x), ptr(y), n, h, w, c, p, stream()))
+        ctx.cfg = (n, h, w, c, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c, p = ctx.cfg
+        dy = _dense(dy)
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+        check(lib.gan_reflect_pad_bwd(ptr(dy), ptr(dx), n, h, w, c, p, stream()))
+        return dx, None
+
+
+def reflect_pad(x, p):
+    """tf.pad(x, [[0,0],[p,p],[p,p],[0,0]], "REFLECT") (cyclegan_module.py:106,108,124,143)."""
+    if p == 0:
+        return x
+    return _ReflectPadFn.apply(x, int(p))
+
+
+# --------------------------------------------------------------------------------------------
+# losses.  Each is fused with its gradient and is a ROOT of the backward pass: the value handed
+# to backward() is taken to be 1 and the loss's weight in the objective is the `weight` argument.
+# --------------------------------------------------------------------------------------------
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, x, other, target, weight):
+        x = _dense(x)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        grad = torch.empty_like(x) if need else None
+        n = x.numel()
+        if kind == 'bce':
+            check(lib.gan_sigmoid_bce_mean(ptr(x), n, target, weight, 0, ptr(loss), ptr(grad), stream()))
+        elif kind == 'mse':
+            check(lib.gan_mse_const_mean(ptr(x), n, target, weight, 0, ptr(loss), ptr(grad), stream()))
+        else:   # l1: x = a (reference side), other = b; the kernel emits d/db
+            other = _dense(other)
+            check(lib.gan_l1_mean(ptr(x), ptr(other), n, weight, 0, ptr(loss), ptr(grad), stream()))
+        ctx.kind = kind
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, _one):
+        g = ctx.grad
+        if ctx.kind == 'l1':
+            ga = None
+            if ctx.needs_input_grad[1]:
+                ga = torch.empty_like(g)
+                check(lib.gan_act_fwd(ptr(g), ptr(ga), g.numel(), _lib.ACT_NONE, 0.0, -1.0, 0.0, stream()))
+            return None, ga, (g if ctx.needs_input_grad[2] else None), None, None
+        return None, g, None, None, None
+
+
+def sigmoid_cross_entropy_mean(logits, label, weight=1.0):
+    """tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits(logits, labels=const)) * weight
+    (dcgan.py:123-134, text2image.py:86-90, cyclegan_module.py:155-156)."""
+    return _LossFn.apply('bce', logits, None, float(label), float(weight))
+
+
+def mse_const_mean(x, target, weight=1.0):
+    """tf.reduce_mean((x - const)**2) * weight: the reference's `mae_criterion` against
+    ones_like / zeros_like (cyclegan_module.py:152-153)."""
+    return _LossFn.apply('mse', x, None, float(target), float(weight))
+
+
+def l1_mean(a, b, weight=1.0):
+    """tf.reduce_mean(tf.abs(a - b)) * weight (abs_criterion, cyclegan_module.py:149-150)."""
+    if a.shape != b.shape:
+        raise ValueError("l1_mean: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
+    return _LossFn.apply('l1', a, b, 0.0, float(weight))
+
+
+_ones = {}
+
+
+def backward(losses):
+    """Run the backward pass from one or several loss roots (their weights are already applied)."""
+    if torch.is_tensor(losses):
+        losses = [losses]
+    dev = losses[0].device
+    one = _ones.get(dev)
+    if one is None:
+        one = _ones[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+    torch.autograd.backward(list(losses), [one] * len(losses))

@@ -1,0 +1,46 @@
+"""tf.train.AdamOptimizer(lr, beta1).minimize(loss, var_list) over one flat arena
+(dcgan.py:154-157, text2image.py:231-232, cyclegan.py:123-130).
+
+The step count lives in device memory and the bias-corrected learning rate is computed on the
+device, so a captured HIP graph of the update replays with the right lr_t at every step.
+Under data parallelism the group's flat gradient arena is all-reduced (sum) in one collective
+and the 1/world_size average is folded into the Adam kernel's gradient scale.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+
+class AdamOptimizer(object):
+    def __init__(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.lr, self.beta1, self.beta2, self.eps = float(learning_rate), float(beta1), float(beta2), float(epsilon)
+        self.group = None
+        self.step_dev = None
+        self.lr_scratch = None
+
+    def attach(self, group):
+        """Bind to a packed variable group (the var_list)."""
+        self.group = group
+        dev = group.values.device
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_scratch = torch.zeros(1, dtype=torch.float32, device=dev)
+        return self
+
+    @property
+    def steps_taken(self):
+        return int(self.step_dev.item())
+
+    def begin(self):
+        self.group.begin_update()
+
+    def apply(self, world_size=1, process_group=None):
+        """Finish the update: zero-fill untouched gradient slots, all-reduce, fused Adam step."""
+        g = self.group
+        g.end_update()
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(g.grads, op=dist.ReduceOp.SUM, group=process_group)
+        check(lib.gan_adam_tf_step(ptr(g.values), ptr(g.grads), ptr(g.m), ptr(g.v), g.numel, self.lr, self.beta1,
+                                   self.beta2, self.eps, 1.0 / float(world_size), ptr(self.step_dev),
+                                   ptr(self.lr_scratch), stream()))

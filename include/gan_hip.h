@@ -1,0 +1,174 @@
+/*
+ * libgan_hip -- C ABI of the MI355X (gfx950) GAN training hot path.
+ *
+ * The reference (Youngjung/GAN) has no FFI: its layer primitives are Python
+ * functions in models/ops.py that hand the arithmetic to TensorFlow-1.x ops.
+ * Each entry point below replaces the TensorFlow op(s) named in its comment,
+ * cited as the reference call site (file:line under the reference root).
+ *
+ * Conventions
+ *   - All tensors are dense fp32, NHWC, in device memory owned by the caller.
+ *   - The library never allocates or frees device memory and never
+ *     synchronises; every launch is asynchronous on the caller's stream.
+ *   - `ws` is a caller-provided scratch buffer of at least the number of bytes
+ *     the matching *_workspace_bytes() query returns (it may be NULL when that
+ *     query returns 0).
+ *   - Return value 0 = success; non-zero = error, text in gan_last_error()
+ *     (thread-local).  Nothing is launched when an argument check fails.
+ *   - Results are deterministic: no floating-point atomics are used.
+ */
+#ifndef GAN_HIP_H
+#define GAN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gan_stream_t; /* a hipStream_t */
+
+/* Geometry shared by conv2d and conv2d_transpose.  "big" is the strided side
+ * (conv2d input / conv2d_transpose output), "small" the other side
+ * (conv2d output / conv2d_transpose input).  The filter is always
+ * [kh][kw][cb][cs]: that is HWIO for conv2d (ops.py:66) and
+ * [height, width, output_channels, in_channels] for conv2d_transpose
+ * (ops.py:80-81).  pt/pl are TensorFlow's pad_before for rows/columns
+ * (SAME: ((ceil(hb/sh)-1)*sh + kh - hb)/2 rounded down; VALID: 0). */
+typedef struct gan_conv_geom {
+    int n;          /* batch */
+    int hb, wb, cb; /* big side: height, width, channels */
+    int hs, ws, cs; /* small side */
+    int kh, kw;     /* filter taps */
+    int sh, sw;     /* strides (1 or 2) */
+    int pt, pl;     /* pad before (top, left) */
+} gan_conv_geom;
+
+/* Activation selectors for the fused epilogues. */
+enum {
+    GAN_ACT_NONE = 0,
+    GAN_ACT_RELU = 1,    /* tf.nn.relu   (dcgan.py:368-380)            */
+    GAN_ACT_LRELU = 2,   /* ops.lrelu    (ops.py:101-102), param = leak */
+    GAN_ACT_TANH = 3,    /* tf.nn.tanh   (dcgan.py:385)                */
+    GAN_ACT_SIGMOID = 4  /* tf.nn.sigmoid(dcgan.py:334,409)            */
+};
+
+const char* gan_last_error(void);
+int gan_abi_version(void);
+
+/* ---- tf.nn.conv2d + tf.nn.bias_add (ops.py:68-71) and their gradients ------------- */
+size_t gan_conv_workspace_bytes(const gan_conv_geom* g);
+/* y[small] = conv(x[big], w) + bias (bias may be NULL) */
+int gan_conv2d_fwd(const gan_conv_geom* g, const float* x, const float* w, const float* bias,
+                   float* y, void* ws, size_t ws_bytes, gan_stream_t stream);
+/* dx[big] = Conv2DBackpropInput(dy[small], w) */
+int gan_conv2d_dgrad(const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                     void* ws, size_t ws_bytes, gan_stream_t stream);
+/* dw (+)= Conv2DBackpropFilter(x[big], dy[small]); db (+)= sum over pixels of dy (db may be NULL).
+ * accumulate != 0 adds into dw/db instead of overwriting (shared weights used twice in a step). */
+int gan_conv2d_wgrad(const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
+                     int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream);
+
+/* ---- tf.nn.conv2d_transpose + bias_add (ops.py:85-94) and their gradients --------- */
+/* y[big] = conv2d_transpose(x[small], w) + bias */
+int gan_deconv2d_fwd(const gan_conv_geom* g, const float* x, const float* w, const float* bias,
+                     float* y, void* ws, size_t ws_bytes, gan_stream_t stream);
+/* dx[small] = conv2d(dy[big], w) */
+int gan_deconv2d_dgrad(const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                       void* ws, size_t ws_bytes, gan_stream_t stream);
+/* dw (+)= filter gradient with dy[big] as the conv input and x[small] as its output gradient;
+ * db (+)= sum over pixels of dy[big] */
+int gan_deconv2d_wgrad(const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
+                       int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream);
+
+/* ---- tf.matmul(input_, matrix) + bias (ops.py:113-115) and its gradients ----------- */
+size_t gan_linear_workspace_bytes(int rows, int in_dim, int out_dim);
+int gan_linear_fwd(int rows, int in_dim, int out_dim, const float* x, const float* matrix,
+                   const float* bias, float* y, void* ws, size_t ws_bytes, gan_stream_t stream);
+int gan_linear_dgrad(int rows, int in_dim, int out_dim, const float* dy, const float* matrix,
+                     float* dx, void* ws, size_t ws_bytes, gan_stream_t stream);
+int gan_linear_wgrad(int rows, int in_dim, int out_dim, const float* x, const float* dy,
+                     float* dmatrix, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                     gan_stream_t stream);
+
+/* ---- tf.contrib.layers.batch_norm (ops.py:38-44), fused with the activation that follows it
+ * x is viewed as [groups][rows][c]; statistics are per (group, channel) over `rows`.
+ * groups == 1 is batch norm; groups == batch with rows == H*W is instance norm (an extension:
+ * the reference's CycleGAN gets it implicitly from batch_norm at batch 1).
+ * Training forward: y = act(gamma*(x-mean)*rsqrt(var+eps)+beta) + residual (residual may be NULL),
+ * biased variance; saves mean and rstd ([groups][c] each) for the backward; when moving_mean /
+ * moving_var are non-NULL (groups must be 1) updates them in place:
+ * moving = momentum*moving + (1-momentum)*batch, with the batch variance multiplied by
+ * rows/(rows-1) when unbiased_moving_var != 0. */
+size_t gan_bn_workspace_bytes(int groups, int rows, int c);
+int gan_bn_fwd_train(const float* x, const float* gamma, const float* beta, float* moving_mean,
+                     float* moving_var, const float* residual, float* y, float* save_mean,
+                     float* save_rstd, int groups, int rows, int c, float eps, float momentum,
+                     int unbiased_moving_var, int act, float act_param, void* ws, size_t ws_bytes,
+                     gan_stream_t stream);
+/* Inference forward (train=False, dcgan.py:427-436): uses the moving statistics. */
+int gan_bn_fwd_eval(const float* x, const float* gamma, const float* beta, const float* moving_mean,
+                    const float* moving_var, float* y, int rows, int c, float eps, int act,
+                    float act_param, gan_stream_t stream);
+/* Backward of the training forward (without the residual term, whose gradient is dy itself):
+ * dx, and dgamma/dbeta (+)= when accumulate != 0.  dx may be NULL (input needs no gradient). */
+int gan_bn_bwd(const float* x, const float* gamma, const float* beta, const float* save_mean,
+               const float* save_rstd, const float* dy, float* dx, float* dgamma, float* dbeta,
+               int accumulate, int groups, int rows, int c, int act, float act_param, void* ws,
+               size_t ws_bytes, gan_stream_t stream);
+
+/* ---- stand-alone activations (ops.py:101-102; dcgan.py:334,368-385,409; text2image.py:198)
+ * forward: y = act(x)*scale + shift; backward from the saved y: dx = dy*scale*act'(.) */
+int gan_act_fwd(const float* x, float* y, long n, int act, float act_param, float scale, float shift,
+                gan_stream_t stream);
+int gan_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float act_param,
+                float scale, float shift, gan_stream_t stream);
+/* y = a + b (residual add, cyclegan_module.py:110) */
+int gan_add_fwd(const float* a, const float* b, float* y, long n, gan_stream_t stream);
+
+/* ---- concat / conv_cond_concat (ops.py:23-28, 57-62; text2image.py:213-217) -----------
+ * out[r][0:ca] = a[r][:], out[r][ca:ca+cb] = b[r / rows_per_b][:]   (rows_per_b = H*W broadcasts a
+ * per-sample vector over the feature map; rows_per_b = 1 is a plain last-axis concat).
+ * backward: da = dout[:, :ca]; db[g] = sum over the group's rows of dout[:, ca:].  da / db may be NULL. */
+int gan_concat_fwd(const float* a, const float* b, float* out, long rows, int ca, int cb,
+                   int rows_per_b, gan_stream_t stream);
+int gan_concat_bwd(const float* dout, float* da, float* db, long rows, int ca, int cb,
+                   int rows_per_b, gan_stream_t stream);
+
+/* ---- tf.pad(..., "REFLECT") (cyclegan_module.py:106,108,124,143) ----------------------- */
+int gan_reflect_pad_fwd(const float* x, float* y, int n, int h, int w, int c, int p,
+                        gan_stream_t stream);
+int gan_reflect_pad_bwd(const float* dy, float* dx, int n, int h, int w, int c, int p,
+                        gan_stream_t stream);
+
+/* ---- losses, fused with their gradient -------------------------------------------------
+ * Each writes loss_out[0] = (accumulate ? loss_out[0] : 0) + weight*loss and, when the gradient
+ * pointer is non-NULL, grad = weight * dloss/dinput.
+ * sigmoid BCE: mean(max(x,0) - x*label + log1p(exp(-|x|)))  (dcgan.py:123-134, text2image.py:86-90,
+ *              cyclegan_module.py:155-156)
+ * mse const:   mean((x-target)^2)                             (cyclegan_module.py:152-153)
+ * l1:          mean(|a-b|), gradient w.r.t. b                 (cyclegan_module.py:149-150) */
+int gan_sigmoid_bce_mean(const float* logits, long n, float label, float weight, int accumulate,
+                         float* loss_out, float* dlogits, gan_stream_t stream);
+int gan_mse_const_mean(const float* x, long n, float target, float weight, int accumulate,
+                       float* loss_out, float* dx, gan_stream_t stream);
+int gan_l1_mean(const float* a, const float* b, long n, float weight, int accumulate,
+                float* loss_out, float* db, gan_stream_t stream);
+
+/* ---- tf.train.AdamOptimizer(lr, beta1).minimize (dcgan.py:154-157) ----------------------
+ * One fused step over a flat parameter group.  step_dev[0] (device int32) holds the number of
+ * steps already taken; the call increments it, computes
+ * lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) on the device (so a captured graph replays correctly) and
+ * applies  m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; theta -= lr_t*m/(sqrt(v)+eps)
+ * with g = grad*grad_scale.  lr_scratch is one device float. */
+int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n, float lr,
+                     float beta1, float beta2, float eps, float grad_scale, int* step_dev,
+                     float* lr_scratch, gan_stream_t stream);
+
+/* ---- utilities ------------------------------------------------------------------------- */
+int gan_fill(float* x, long n, float value, gan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAN_HIP_H */

@@ -1,0 +1,429 @@
+"""GPU parity of every C-ABI entry point against the float64 numpy oracle, on identical seeded
+inputs.  Calls go through ctypes into libgan_hip.so (torch only owns the device memory)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(2024)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from gan_amd import _lib
+    return _lib
+
+
+def _ws(L, g):
+    n = int(L.lib.gan_conv_workspace_bytes(ctypes.byref(g)))
+    return L.workspace(n)
+
+
+# n, h, w, cb, cs, k, s, padding   (conv2d: x is [n,h,w,cb] -> y [n,hs,ws,cs])
+SMALL_CONVS = [
+    (2, 8, 8, 3, 4, 5, 2, 'SAME'),
+    (2, 7, 7, 5, 6, 5, 2, 'SAME'),
+    (3, 28, 28, 11, 11, 5, 2, 'SAME'),     # MNIST d_h0 (odd channels -> scalar load path)
+    (3, 14, 14, 21, 74, 5, 2, 'SAME'),     # MNIST d_h1
+    (4, 4, 4, 24, 16, 1, 1, 'SAME'),       # 1x1
+    (1, 12, 12, 4, 8, 3, 2, 'SAME'),       # cyclegan 3x3 s2, pad (0,1)
+    (1, 10, 10, 8, 8, 3, 1, 'VALID'),
+    (1, 22, 22, 3, 8, 7, 1, 'VALID'),
+    (1, 16, 16, 12, 1, 5, 1, 'SAME'),      # cyclegan d_h3_pred: Cout = 1
+    (2, 9, 13, 8, 12, 5, 2, 'SAME'),       # non-square, odd
+]
+
+DCGAN_CONVS = [
+    (64, 64, 64, 3, 64, 5, 2, 'SAME'),     # d_h0
+    (64, 32, 32, 64, 128, 5, 2, 'SAME'),   # d_h1
+    (64, 16, 16, 128, 256, 5, 2, 'SAME'),  # d_h2
+    (64, 8, 8, 256, 512, 5, 2, 'SAME'),    # d_h3
+]
+
+
+def _conv_case(L, case, cfg=None, splits=None):
+    from gpu_util import assert_close, dev, forced, geom_for, host
+    n, h, w, cb, cs, k, s, padding = case
+    x = RNG.standard_normal((n, h, w, cb)).astype(np.float32)
+    wt = (RNG.standard_normal((k, k, cb, cs)) * 0.05).astype(np.float32)
+    b = RNG.standard_normal(cs).astype(np.float32)
+    g = geom_for(n, h, w, cb, cs, k, s, padding)
+    x64, w64 = x.astype(np.float64), wt.astype(np.float64)
+    y_ref = T.conv2d_forward(x64, w64, s, s, padding) + b
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = T.conv2d_backward_input(dy.astype(np.float64), w64, x.shape, s, s, padding)
+    dw_ref = T.conv2d_backward_filter(x64, dy.astype(np.float64), k, k, s, s, padding)
+    db_ref = T.bias_add_backward(dy.astype(np.float64))
+    xd, wd, bd, dyd = dev(x), dev(wt), dev(b), dev(dy)
+    y = torch.empty(y_ref.shape, device='cuda')
+    dx = torch.empty(x.shape, device='cuda')
+    dw0 = RNG.standard_normal(wt.shape).astype(np.float32)
+    db0 = RNG.standard_normal(cs).astype(np.float32)
+    dw, db = dev(dw0), dev(db0)
+    wp, wn = _ws(L, g)
+    st = L.stream()
+    with forced(cfg, splits):
+        L.check(L.lib.gan_conv2d_fwd(ctypes.byref(g), L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(y), wp, wn, st))
+        L.check(L.lib.gan_conv2d_dgrad(ctypes.byref(g), L.ptr(dyd), L.ptr(wd), L.ptr(dx), wp, wn, st))
+        L.check(L.lib.gan_conv2d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(db), 0, wp, wn, st))
+        torch.cuda.synchronize()
+        assert_close(host(y), y_ref, "conv2d fwd %s" % (case,))
+        assert_close(host(dx), dx_ref, "conv2d dgrad %s" % (case,))
+        assert_close(host(dw), dw_ref, "conv2d wgrad %s" % (case,))
+        assert_close(host(db), db_ref, "conv2d bias grad %s" % (case,))
+        # accumulate: a second call adds onto what is there
+        L.check(L.lib.gan_conv2d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(db), 1, wp, wn, st))
+        torch.cuda.synchronize()
+        assert_close(host(dw), 2 * dw_ref, "conv2d wgrad accumulate %s" % (case,))
+        assert_close(host(db), 2 * db_ref, "conv2d bias grad accumulate %s" % (case,))
+
+
+@pytest.mark.parametrize("case", SMALL_CONVS)
+def test_conv2d_small(L, case):
+    _conv_case(L, case)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv2d_every_tile_config_and_split(L, cfg, splits):
+    _conv_case(L, (2, 12, 12, 8, 40, 5, 2, 'SAME'), cfg, splits)
+    _conv_case(L, (2, 9, 9, 5, 7, 3, 1, 'SAME'), cfg, splits)
+
+
+@pytest.mark.parametrize("case", DCGAN_CONVS)
+def test_conv2d_dcgan64_shapes(L, case):
+    _conv_case(L, case)
+
+
+# n, hs, ws, cs(in), cb(out), k, s, out_h, out_w   (deconv2d: x [n,hs,ws,cs] -> y [n,oh,ow,cb])
+SMALL_DECONVS = [
+    (2, 4, 4, 8, 4, 5, 2, 8, 8),
+    (2, 4, 4, 6, 3, 5, 2, 7, 7),
+    (3, 7, 7, 138, 128, 5, 2, 14, 14),   # MNIST g_h2
+    (3, 14, 14, 138, 1, 5, 2, 28, 28),   # MNIST g_h3: Cout = 1
+    (1, 8, 8, 8, 4, 3, 2, 16, 16),       # cyclegan 3x3 s2
+    (2, 5, 6, 4, 12, 5, 2, 9, 11),       # odd, non-square
+]
+
+DCGAN_DECONVS = [
+    (64, 4, 4, 512, 256, 5, 2, 8, 8),      # g_h1
+    (64, 8, 8, 256, 128, 5, 2, 16, 16),    # g_h2
+    (64, 16, 16, 128, 64, 5, 2, 32, 32),   # g_h3
+    (64, 32, 32, 64, 3, 5, 2, 64, 64),     # g_h4
+]
+
+
+def _deconv_case(L, case, cfg=None, splits=None):
+    from gpu_util import assert_close, dev, forced, geom_for, host
+    n, hs, ws_, cs, cb, k, s, oh, ow = case
+    x = RNG.standard_normal((n, hs, ws_, cs)).astype(np.float32)
+    wt = (RNG.standard_normal((k, k, cb, cs)) * 0.05).astype(np.float32)
+    b = RNG.standard_normal(cb).astype(np.float32)
+    g = geom_for(n, oh, ow, cb, cs, k, s, 'SAME')
+    assert (g.hs, g.ws) == (hs, ws_)
+    x64, w64 = x.astype(np.float64), wt.astype(np.float64)
+    y_ref = T.conv2d_transpose_forward(x64, w64, (n, oh, ow, cb), s, s) + b
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = T.conv2d_transpose_backward_input(dy.astype(np.float64), w64, s, s)
+    dw_ref = T.conv2d_transpose_backward_filter(x64, dy.astype(np.float64), k, k, s, s)
+    db_ref = T.bias_add_backward(dy.astype(np.float64))
+    xd, wd, bd, dyd = dev(x), dev(wt), dev(b), dev(dy)
+    y = torch.empty(y_ref.shape, device='cuda')
+    dx = torch.empty(x.shape, device='cuda')
+    dw = torch.empty(wt.shape, device='cuda')
+    db = torch.empty(cb, device='cuda')
+    wp, wn = _ws(L, g)
+    st = L.stream()
+    with forced(cfg, splits):
+        L.check(L.lib.gan_deconv2d_fwd(ctypes.byref(g), L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(y), wp, wn, st))
+        L.check(L.lib.gan_deconv2d_dgrad(ctypes.byref(g), L.ptr(dyd), L.ptr(wd), L.ptr(dx), wp, wn, st))
+        L.check(L.lib.gan_deconv2d_wgrad(ctypes.byref(g), L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(db), 0, wp, wn, st))
+        torch.cuda.synchronize()
+    assert_close(host(y), y_ref, "deconv2d fwd %s" % (case,))
+    assert_close(host(dx), dx_ref, "deconv2d dgrad %s" % (case,))
+    assert_close(host(dw), dw_ref, "deconv2d wgrad %s" % (case,))
+    assert_close(host(db), db_ref, "deconv2d bias grad %s" % (case,))
+
+
+@pytest.mark.parametrize("case", SMALL_DECONVS)
+def test_deconv2d_small(L, case):
+    _deconv_case(L, case)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("splits", [1, 2])
+def test_deconv2d_every_tile_config_and_split(L, cfg, splits):
+    _deconv_case(L, (2, 6, 6, 8, 36, 5, 2, 12, 12), cfg, splits)
+    _deconv_case(L, (2, 5, 5, 3, 5, 3, 2, 9, 9), cfg, splits)
+
+
+@pytest.mark.parametrize("case", DCGAN_DECONVS)
+def test_deconv2d_dcgan64_shapes(L, case):
+    _deconv_case(L, case)
+
+
+def test_deconv2d_is_adjoint_of_conv2d_on_device(L):
+    """Size-independent property at the full DCGAN g_h2 size: <conv2d(u, w), x> == <u, deconv2d(x, w)>."""
+    from gpu_util import dev, geom_for
+    n, hs, cs, cb, oh = 64, 8, 256, 128, 16
+    g = geom_for(n, oh, oh, cb, cs, 5, 2, 'SAME')
+    x = dev(RNG.standard_normal((n, hs, hs, cs)))
+    u = dev(RNG.standard_normal((n, oh, oh, cb)))
+    wd = dev(RNG.standard_normal((5, 5, cb, cs)) * 0.05)
+    y = torch.empty((n, oh, oh, cb), device='cuda')
+    cu = torch.empty((n, hs, hs, cs), device='cuda')
+    wp, wn = _ws(L, g)
+    L.check(L.lib.gan_deconv2d_fwd(ctypes.byref(g), L.ptr(x), L.ptr(wd), None, L.ptr(y), wp, wn, L.stream()))
+    L.check(L.lib.gan_conv2d_fwd(ctypes.byref(g), L.ptr(u), L.ptr(wd), None, L.ptr(cu), wp, wn, L.stream()))
+    lhs = float((cu.double() * x.double()).sum())
+    rhs = float((u.double() * y.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs))
+
+
+@pytest.mark.parametrize("rows,i,o", [(64, 100, 8192), (64, 8192, 1), (64, 110, 1024), (64, 1034, 6272),
+                                      (64, 3636, 1024), (5, 7, 3), (64, 1024, 256)])
+def test_linear(L, rows, i, o):
+    from gpu_util import assert_close, dev, host
+    x = RNG.standard_normal((rows, i)).astype(np.float32)
+    m = (RNG.standard_normal((i, o)) * 0.05).astype(np.float32)
+    b = RNG.standard_normal(o).astype(np.float32)
+    dy = RNG.standard_normal((rows, o)).astype(np.float32)
+    y_ref = T.linear_forward(x.astype(np.float64), m.astype(np.float64), b.astype(np.float64))
+    dx_ref, dm_ref, db_ref = T.linear_backward(x.astype(np.float64), m.astype(np.float64), dy.astype(np.float64))
+    xd, md, bd, dyd = dev(x), dev(m), dev(b), dev(dy)
+    y, dx = torch.empty((rows, o), device='cuda'), torch.empty((rows, i), device='cuda')
+    dm, db = torch.empty((i, o), device='cuda'), torch.empty(o, device='cuda')
+    wp, wn = L.workspace(int(L.lib.gan_linear_workspace_bytes(rows, i, o)))
+    st = L.stream()
+    L.check(L.lib.gan_linear_fwd(rows, i, o, L.ptr(xd), L.ptr(md), L.ptr(bd), L.ptr(y), wp, wn, st))
+    L.check(L.lib.gan_linear_dgrad(rows, i, o, L.ptr(dyd), L.ptr(md), L.ptr(dx), wp, wn, st))
+    L.check(L.lib.gan_linear_wgrad(rows, i, o, L.ptr(xd), L.ptr(dyd), L.ptr(dm), L.ptr(db), 0, wp, wn, st))
+    torch.cuda.synchronize()
+    assert_close(host(y), y_ref, "linear fwd")
+    assert_close(host(dx), dx_ref, "linear dgrad")
+    assert_close(host(dm), dm_ref, "linear wgrad")
+    assert_close(host(db), db_ref, "linear bias grad")
+
+
+ACTS = [(0, 0.0), (1, 0.0), (2, 0.2), (3, 0.0), (4, 0.0)]
+
+
+def _act_ref(z, act, p):
+    return [z, T.relu(z), T.lrelu(z, p), np.tanh(z), T.sigmoid(z)][act]
+
+
+def _act_grad_ref(z, a, act, p):
+    return [np.ones_like(z), (z > 0).astype(z.dtype), np.where(z >= 0, 1.0, p), 1 - a * a, a * (1 - a)][act]
+
+
+@pytest.mark.parametrize("shape,groups", [((64, 16, 16, 128), 1), ((64, 4, 4, 512), 1), ((64, 1024), 1),
+                                          ((64, 6272), 1), ((5, 7, 7, 74), 1), ((1, 32, 32, 3), 1),
+                                          ((3, 8, 8, 12), 3), ((64, 32, 32, 64), 1)])
+@pytest.mark.parametrize("act,param", ACTS)
+def test_batch_norm_train(L, shape, groups, act, param):
+    from gpu_util import assert_close, dev, host
+    c = shape[-1]
+    rows = int(np.prod(shape)) // c // groups
+    x = (RNG.standard_normal(shape) * 1.7 + 0.8).astype(np.float32)
+    gamma = (RNG.standard_normal(c) * 0.3 + 1).astype(np.float32)
+    beta = (RNG.standard_normal(c) * 0.3).astype(np.float32)
+    res = RNG.standard_normal(shape).astype(np.float32)
+    dy = RNG.standard_normal(shape).astype(np.float32)
+    mm0, mv0 = RNG.standard_normal(c).astype(np.float32), (RNG.random(c) + 0.5).astype(np.float32)
+    x64 = x.astype(np.float64).reshape(groups, rows, c)
+    if act in (1, 2):
+        # relu / lrelu have a kink at z == 0: where the fp32 and fp64 pre-activations could land on
+        # different sides of it, take the element out of the gradient comparison (dy = 0 there)
+        for gi in range(groups):
+            z, _, _, _ = T.batch_norm_train_forward(x64[gi], gamma.astype(np.float64), beta.astype(np.float64), 1e-5)
+            dy.reshape(groups, rows, c)[gi][np.abs(z) < 1e-3] = 0.0
+    z_ref = np.empty_like(x64)
+    dx_ref = np.empty_like(x64)
+    dg_ref, db_ref = np.zeros(c), np.zeros(c)
+    means, variances = [], []
+    for gi in range(groups):
+        z, mean, var, rstd = T.batch_norm_train_forward(x64[gi], gamma.astype(np.float64), beta.astype(np.float64), 1e-5)
+        z_ref[gi] = z
+        a = _act_ref(z, act, param)
+        dz = dy.astype(np.float64).reshape(groups, rows, c)[gi] * _act_grad_ref(z, a, act, param)
+        dx_ref[gi], dg, db = T.batch_norm_train_backward(x64[gi], gamma.astype(np.float64), mean, rstd, dz)
+        dg_ref += dg
+        db_ref += db
+        means.append(mean)
+        variances.append(var)
+    y_ref = _act_ref(z_ref, act, param).reshape(shape) + res
+    xd, gd, bd, rd, dyd = dev(x), dev(gamma), dev(beta), dev(res), dev(dy)
+    mm, mv = (dev(mm0), dev(mv0)) if groups == 1 else (None, None)
+    y, dx = torch.empty(shape, device='cuda'), torch.empty(shape, device='cuda')
+    sm, sr = torch.empty(groups * c, device='cuda'), torch.empty(groups * c, device='cuda')
+    dgam, dbet = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    wp, wn = L.workspace(int(L.lib.gan_bn_workspace_bytes(groups, rows, c)))
+    st = L.stream()
+    L.check(L.lib.gan_bn_fwd_train(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(mm), L.ptr(mv), L.ptr(rd), L.ptr(y), L.ptr(sm),
+                                   L.ptr(sr), groups, rows, c, 1e-5, 0.9, 0, act, param, wp, wn, st))
+    L.check(L.lib.gan_bn_bwd(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(sm), L.ptr(sr), L.ptr(dyd), L.ptr(dx), L.ptr(dgam),
+                             L.ptr(dbet), 0, groups, rows, c, act, param, wp, wn, st))
+    torch.cuda.synchronize()
+    assert_close(host(y), y_ref, "bn fwd")
+    assert_close(host(sm), np.concatenate(means), "bn saved mean")
+    assert_close(host(dx).reshape(groups, rows, c), dx_ref, "bn dx", tol=2e-4 if rows < 8 else 1e-4)
+    assert_close(host(dgam), dg_ref, "bn dgamma")
+    assert_close(host(dbet), db_ref, "bn dbeta")
+    if groups == 1:
+        mm_ref, mv_ref = T.batch_norm_moving_update(mm0.astype(np.float64), mv0.astype(np.float64), means[0],
+                                                    variances[0], 0.9, rows)
+        assert_close(host(mm), mm_ref, "moving mean")
+        assert_close(host(mv), mv_ref, "moving variance")
+        # inference path on the updated moving statistics
+        ye = torch.empty(shape, device='cuda')
+        L.check(L.lib.gan_bn_fwd_eval(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(mm), L.ptr(mv), L.ptr(ye), rows, c, 1e-5,
+                                      act, param, st))
+        torch.cuda.synchronize()
+        ze = T.batch_norm_eval_forward(x.astype(np.float64), gamma, beta, mm_ref, mv_ref, 1e-5)
+        assert_close(host(ye), _act_ref(ze, act, param), "bn eval")
+
+
+def test_batch_norm_unbiased_moving_variance_flag(L):
+    from gpu_util import assert_close, dev, host
+    shape, c = (8, 4, 4, 16), 16
+    rows = 128
+    x = RNG.standard_normal(shape).astype(np.float32)
+    xd, gd, bd = dev(x), dev(np.ones(c)), dev(np.zeros(c))
+    mm, mv = dev(np.zeros(c)), dev(np.ones(c))
+    y, sm, sr = torch.empty(shape, device='cuda'), torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    wp, wn = L.workspace(int(L.lib.gan_bn_workspace_bytes(1, rows, c)))
+    L.check(L.lib.gan_bn_fwd_train(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(mm), L.ptr(mv), None, L.ptr(y), L.ptr(sm),
+                                   L.ptr(sr), 1, rows, c, 1e-5, 0.9, 1, 0, 0.0, wp, wn, L.stream()))
+    torch.cuda.synchronize()
+    _, mean, var, _ = T.batch_norm_train_forward(x.astype(np.float64), np.ones(c), np.zeros(c), 1e-5)
+    _, mv_ref = T.batch_norm_moving_update(np.zeros(c), np.ones(c), mean, var, 0.9, rows, unbiased_moving_var=True)
+    assert_close(host(mv), mv_ref, "unbiased moving variance")
+
+
+@pytest.mark.parametrize("act,param", ACTS[1:])
+@pytest.mark.parametrize("scale,shift", [(1.0, 0.0), (0.5, 0.5)])
+def test_activations(L, act, param, scale, shift):
+    from gpu_util import assert_close, dev, host
+    x = (RNG.standard_normal(10007) * 2).astype(np.float32)
+    x[:3] = [0.0, -0.0, 1e-30]
+    if (scale, shift) != (1.0, 0.0) and act in (1, 2):
+        xd = dev(x)
+        assert L.lib.gan_act_fwd(L.ptr(xd), L.ptr(xd), x.size, act, param, scale, shift, L.stream()) != 0
+        assert b"not supported" in L.lib.gan_last_error()
+        return
+    dy = RNG.standard_normal(10007).astype(np.float32)
+    a = _act_ref(x.astype(np.float64), act, param)
+    xd, dyd = dev(x), dev(dy)
+    y, dx = torch.empty_like(xd), torch.empty_like(xd)
+    L.check(L.lib.gan_act_fwd(L.ptr(xd), L.ptr(y), x.size, act, param, scale, shift, L.stream()))
+    L.check(L.lib.gan_act_bwd(L.ptr(y), L.ptr(dyd), L.ptr(dx), x.size, act, param, scale, shift, L.stream()))
+    torch.cuda.synchronize()
+    assert_close(host(y), a * scale + shift, "act fwd")
+    assert_close(host(dx), dy * scale * _act_grad_ref(x.astype(np.float64), a, act, param), "act bwd", tol=2e-4)
+
+
+def test_add_fill_concat_reflect(L):
+    from gpu_util import assert_close, dev, host
+    a, b = RNG.standard_normal(1001).astype(np.float32), RNG.standard_normal(1001).astype(np.float32)
+    ad, bd = dev(a), dev(b)
+    y = torch.empty_like(ad)
+    L.check(L.lib.gan_add_fwd(L.ptr(ad), L.ptr(bd), L.ptr(y), 1001, L.stream()))
+    L.check(L.lib.gan_fill(L.ptr(ad), 1001, 3.5, L.stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host(y), a + b)
+    assert np.all(host(ad) == 3.5)
+    # conv_cond_concat and plain concat
+    for shape_x, cy, rpb in [((3, 7, 7, 5), 10, 49), ((4, 4, 4, 512), 256, 16), ((6, 37), 10, 1)]:
+        x = RNG.standard_normal(shape_x).astype(np.float32)
+        n = shape_x[0]
+        yv = RNG.standard_normal((n, cy)).astype(np.float32)
+        ref = (T.conv_cond_concat(x, yv.reshape(n, 1, 1, cy)) if len(shape_x) == 4
+               else np.concatenate([x, yv], axis=1))
+        out = torch.empty(ref.shape, device='cuda')
+        rows = int(np.prod(shape_x[:-1]))
+        L.check(L.lib.gan_concat_fwd(L.ptr(dev(x)), L.ptr(dev(yv)), L.ptr(out), rows, shape_x[-1], cy, rpb, L.stream()))
+        dout = RNG.standard_normal(ref.shape).astype(np.float32)
+        da, db = torch.empty(shape_x, device='cuda'), torch.empty((n, cy), device='cuda')
+        L.check(L.lib.gan_concat_bwd(L.ptr(dev(dout)), L.ptr(da), L.ptr(db), rows, shape_x[-1], cy, rpb, L.stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(host(out), ref)
+        np.testing.assert_array_equal(host(da), dout[..., :shape_x[-1]])
+        db_ref = dout[..., shape_x[-1]:].astype(np.float64).reshape(n, -1, cy).sum(axis=1)
+        assert_close(host(db), db_ref, "concat db")
+    for p, shape in [(1, (2, 6, 5, 8)), (3, (1, 9, 11, 3)), (3, (1, 4, 4, 2))]:
+        x = RNG.standard_normal(shape).astype(np.float32)
+        ref = T.reflect_pad(x, p)
+        out = torch.empty(ref.shape, device='cuda')
+        n, h, w, c = shape
+        L.check(L.lib.gan_reflect_pad_fwd(L.ptr(dev(x)), L.ptr(out), n, h, w, c, p, L.stream()))
+        dyv = RNG.standard_normal(ref.shape).astype(np.float32)
+        dx = torch.empty(shape, device='cuda')
+        L.check(L.lib.gan_reflect_pad_bwd(L.ptr(dev(dyv)), L.ptr(dx), n, h, w, c, p, L.stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(host(out), ref)
+        assert_close(host(dx), T.reflect_pad_backward(dyv.astype(np.float64), p), "reflect pad bwd")
+
+
+def test_losses(L):
+    from gpu_util import assert_close, dev, host
+    for n in (64, 1024, 3 * 32 * 32, 50000):
+        x = (RNG.standard_normal(n) * 3).astype(np.float32)
+        xd = dev(x)
+        loss = torch.zeros(1, device='cuda')
+        g = torch.empty(n, device='cuda')
+        for label in (0.0, 1.0):
+            L.check(L.lib.gan_sigmoid_bce_mean(L.ptr(xd), n, label, 1.0, 0, L.ptr(loss), L.ptr(g), L.stream()))
+            torch.cuda.synchronize()
+            lref, gref = T.sigmoid_cross_entropy_mean(x.astype(np.float64), label)
+            assert_close(host(loss), [lref], "bce loss")
+            assert_close(host(g), gref, "bce grad")
+        L.check(L.lib.gan_mse_const_mean(L.ptr(xd), n, 1.0, 0.5, 1, L.ptr(loss), L.ptr(g), L.stream()))
+        torch.cuda.synchronize()
+        l2, g2 = T.mse_mean(x.astype(np.float64), np.ones(n))
+        assert_close(host(loss), [lref + 0.5 * l2], "mse accumulate")
+        assert_close(host(g), 0.5 * g2, "mse grad")
+        b = RNG.standard_normal(n).astype(np.float32)
+        L.check(L.lib.gan_l1_mean(L.ptr(xd), L.ptr(dev(b)), n, 10.0, 0, L.ptr(loss), L.ptr(g), L.stream()))
+        torch.cuda.synchronize()
+        l1, g1 = T.l1_mean(x.astype(np.float64), b.astype(np.float64))
+        assert_close(host(loss), [10 * l1], "l1 loss")
+        assert_close(host(g), -10 * g1, "l1 grad w.r.t. b")
+
+
+def test_adam_tf_steps(L):
+    from gpu_util import assert_close, dev, host
+    n = 100003
+    theta = RNG.standard_normal(n).astype(np.float32)
+    th, m, v = dev(theta), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    lr_s = torch.zeros(1, device='cuda')
+    rt, rm, rv = theta.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, 6):
+        g = (RNG.standard_normal(n) * 0.01).astype(np.float32)
+        L.check(L.lib.gan_adam_tf_step(L.ptr(th), L.ptr(dev(g * 4)), L.ptr(m), L.ptr(v), n, 2e-4, 0.5, 0.999, 1e-8, 0.25,
+                                       L.ptr(step), L.ptr(lr_s), L.stream()))
+        rt, rm, rv = T.adam_tf_step(rt, g.astype(np.float64), rm, rv, t, 2e-4, 0.5)
+    torch.cuda.synchronize()
+    assert int(step.item()) == 5
+    assert_close(host(th), rt, "adam theta", tol=1e-6)
+    assert_close(host(m), rm, "adam m")
+    assert_close(host(v), rv, "adam v")
+
+
+def test_argument_errors_are_reported(L):
+    from gpu_util import dev, geom_for
+    g = geom_for(1, 8, 8, 4, 4, 5, 2, 'SAME')
+    x = dev(np.zeros((1, 8, 8, 4)))
+    rc = L.lib.gan_conv2d_fwd(ctypes.byref(g), L.ptr(x), None, None, L.ptr(x), None, 0, L.stream())
+    assert rc != 0 and b"NULL" in L.lib.gan_last_error()
+    bad = geom_for(1, 8, 8, 4, 4, 5, 2, 'SAME')
+    bad.sh = 3
+    assert L.lib.gan_conv2d_fwd(ctypes.byref(bad), L.ptr(x), L.ptr(x), None, L.ptr(x), None, 0, L.stream()) != 0
+    assert b"stride" in L.lib.gan_last_error()
+    with pytest.raises(L.GanHipError):
+        L.ptr(torch.zeros(4))          # host tensor: no CPU path
