@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""DCGAN-64 G+D training throughput on MI355X (the headline metric of BASELINE.json).
+
+One step = one iteration of the reference's loop body (models/dcgan.py:262-275): one D update and
+two G updates on a batch of 64 synthetic 64x64x3 images per GPU, fp32, inputs resident in HBM.
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run,
+one rank per GPU, gradients all-reduced with RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak
+BATCH = 64
+
+
+def dcgan64_opts(seed):
+    return argparse.Namespace(model='DCGAN', dataset='celebA', batch_size=BATCH, input_height=108, input_width=108,
+                              output_height=64, output_width=64, y_dim=None, z_dim=100, gf_dim=64, df_dim=64,
+                              gfc_dim=1024, dfc_dim=1024, c_dim=3, lr=0.0002, beta1=0.5, crop=True, nEpochs=1,
+                              train_size=1e8, print_every=1, checkpoint_dir='./checkpoint', seed=seed)
+
+
+# nominal FLOPs (2*MAC, every filter tap counted) of one contraction call, from its geometry
+def conv_flops(g):
+    return 2.0 * g.n * g.hs * g.ws * g.cs * g.kh * g.kw * g.cb
+
+
+class ContractionTimer(object):
+    """Brackets every conv / deconv / linear C-ABI call with HIP events on the launching stream
+    (torch's current stream is the stream the library is given) and tallies nominal FLOPs."""
+
+    CONV = ["gan_conv2d_fwd", "gan_conv2d_dgrad", "gan_conv2d_wgrad",
+            "gan_deconv2d_fwd", "gan_deconv2d_dgrad", "gan_deconv2d_wgrad"]
+    LIN = ["gan_linear_fwd", "gan_linear_dgrad", "gan_linear_wgrad"]
+
+    def __init__(self, L):
+        self.L = L
+        self.records = []
+        self.saved = {}
+
+    def __enter__(self):
+        lib = self.L.lib
+        for name in self.CONV + self.LIN:
+            fn = getattr(lib, name)
+            self.saved[name] = fn
+            setattr(lib, name, self._wrap(name, fn))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.L.lib, name, fn)
+
+    def _wrap(self, name, fn):
+        is_conv = name in self.CONV
+
+        def call(*args):
+            if is_conv:
+                g = args[0]._obj
+                flops = conv_flops(g)
+                shape = (g.n, g.hb, g.wb, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, g.sh)
+            else:
+                flops = 2.0 * args[0] * args[1] * args[2]
+                shape = tuple(args[:3])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self.records.append((name, shape, flops, e0, e1))
+            return rc
+        return call
+
+    def summary(self):
+        torch.cuda.synchronize()
+        per = {}
+        tot_ms = tot_fl = 0.0
+        for name, shape, flops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            k = "%s %s" % (name, "x".join(str(s) for s in shape))
+            a = per.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += flops
+            tot_ms += ms
+            tot_fl += flops
+        return tot_ms, tot_fl, len(self.records), per
+
+
+def cpu_baseline(iters):
+    """The numpy oracle's restatement of the same iteration on the host cores ("port", not TensorFlow)."""
+    from oracle import autodiff as A
+    from oracle import nets
+    rng = np.random.default_rng(0)
+    st = A.Store(seed=0)
+    net = nets.DCGAN(st, batch_size=BATCH)
+    im = rng.uniform(-1, 1, (BATCH, 64, 64, 3)).astype(np.float32)
+    z = rng.uniform(-1, 1, (BATCH, 100)).astype(np.float32)
+    net.build(im, z)
+    t0 = time.time()
+    for _ in range(iters):
+        net.train_iteration(im, z)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": round(BATCH * iters / dt, 3), "unit": "images/s", "cores": int(threads), "kind": "port",
+            "sample": "%d iterations of the numpy oracle's DCGAN-64 step (batch 64, fp32, BLAS threads = cores), "
+                      "CPU restatement, not TensorFlow" % iters}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gan_amd import _lib
+    from gan_amd.dcgan import DCGAN
+
+    model = DCGAN(None, dcgan64_opts(seed=0), world_size=world, load_data=False)
+    # synthetic CelebA-shaped data, per-rank seed, resident in HBM before the timed region
+    rng = np.random.default_rng(1000 + rank)
+    pool = [(torch.from_numpy(rng.uniform(-1, 1, (BATCH, 64, 64, 3)).astype(np.float32)).cuda(),
+             torch.from_numpy(rng.uniform(-1, 1, (BATCH, 100)).astype(np.float32)).cuda()) for _ in range(4)]
+
+    if args.no_graph:
+        run = lambda im, z, y=None: model.train_iteration(im, z, y)
+    else:
+        run = model.iteration_runner(pool[0][0], pool[0][1])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run(*pool[i % len(pool)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = run(*pool[i % len(pool)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = {k: float(v) for k, v in out.items()}
+    if not all(np.isfinite(list(losses.values()))):
+        raise SystemExit("non-finite loss in the timed region: %s" % losses)
+
+    # roofline of the dominant kernel family (the MFMA implicit-GEMM contractions), measured live with
+    # HIP events around every contraction call of eager iterations (graph replay hides single launches)
+    roof = None
+    timer_iters = 3
+    with ContractionTimer(_lib) as tm:
+        for i in range(timer_iters):
+            model.train_iteration(*pool[i % len(pool)])
+        ms, flops, calls, per = tm.summary()
+    achieved = flops / (ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "igemm_kernel (+ reduce_slabs_kernel) over the %d contraction calls of one iteration" % (calls // timer_iters),
+            "flop_per_step": round(flops / timer_iters / 1e9, 2), "kernel_ms_per_step": round(ms / timer_iters, 3)}
+    if args.detail and rank == 0:
+        for k, (n, t_ms, fl) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            sys.stderr.write("%-70s calls %3d  %8.3f ms/iter  %7.2f TFLOP/s\n"
+                             % (k, n // timer_iters, t_ms / timer_iters, fl / (t_ms * 1e-3) / 1e12))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "DCGAN-64 G+D train images/sec", "value": round(BATCH * world * args.steps / elapsed, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DCGAN 64x64x3 CelebA-shaped synthetic images, batch 64 per GPU, fp32, "
+                                   "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
+                       "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments + RCCL all-reduce")},
+            "roofline": roof,
+            "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "losses_last_step": {k: round(v, 5) for k, v in losses.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_iters)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,456 @@
+"""DCGAN on the HIP hot path, mirroring the reference's models/dcgan.py.
+
+Same constructor shape (`DCGAN(sess, options)`), same network wiring (discriminator
+dcgan.py:322-351, generator :353-410, sampler :412-462), same losses and variable split
+(:123-147), same optimisers (:154-157) and the same per-iteration schedule (:226-279): one D
+update, two G updates with the same z, then (optionally) the three logging re-evaluations.
+
+Differences that are deliberate:
+  * define-by-run instead of a TF graph: "building the model" runs each network once on zeros to
+    create the variables in the reference's creation order, then packs the d_/g_ groups into flat
+    arenas;
+  * the reference's defects are not reproduced (pdb.set_trace at :153; the un-imported image
+    helpers at :79,175,211,299,313);
+  * `sess` is accepted and ignored (there is no session); `world_size > 1` adds data-parallel
+    gradient all-reduce, which the reference does not have.
+"""
+from __future__ import division
+
+import math
+import os
+import re
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from . import variables as V
+from .ops import batch_norm, concat, conv2d, conv_cond_concat, deconv2d, linear, lrelu
+from .optim import AdamOptimizer
+
+
+def conv_out_size_same(size, stride):
+    """dcgan.py:15-16"""
+    return int(math.ceil(float(size) / float(stride)))
+
+
+class DCGAN(object):
+    def __init__(self, sess, options, store=None, world_size=1, process_group=None, load_data=True):
+        self.sess = sess
+        self.opts = options
+        self.model = getattr(options, 'model', 'DCGAN')
+        self.crop = getattr(options, 'crop', True)
+
+        self.batch_size = options.batch_size
+        self.sample_num = options.batch_size
+
+        self.input_height = options.input_height
+        self.input_width = options.input_width
+        self.output_height = options.output_height
+        self.output_width = options.output_width
+
+        self.y_dim = options.y_dim
+        self.z_dim = options.z_dim
+        self.gf_dim = options.gf_dim
+        self.df_dim = options.df_dim
+        self.gfc_dim = options.gfc_dim
+        self.dfc_dim = options.dfc_dim
+        self.print_every = getattr(options, 'print_every', 1)
+
+        self.world_size = world_size
+        self.process_group = process_group
+        self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
+
+        # batch normalization : deals with poor initialization helps gradient flow (dcgan.py:56-68)
+        self.d_bn1 = batch_norm(name='d_bn1')
+        self.d_bn2 = batch_norm(name='d_bn2')
+        if not self.y_dim:
+            self.d_bn3 = batch_norm(name='d_bn3')
+        self.g_bn0 = batch_norm(name='g_bn0')
+        self.g_bn1 = batch_norm(name='g_bn1')
+        self.g_bn2 = batch_norm(name='g_bn2')
+        if not self.y_dim:
+            self.g_bn3 = batch_norm(name='g_bn3')
+
+        self.dataset = options.dataset
+        self.input_fname_pattern = getattr(options, 'input_fname_pattern', '*.jpg')
+        self.checkpoint_dir = getattr(options, 'checkpoint_dir', './checkpoint')
+
+        self.data_X = self.data_y = None
+        c_dim = getattr(options, 'c_dim', None)
+        if load_data and self.dataset == 'mnist' and os.path.exists(os.path.join("./data", "mnist", "train-images-idx3-ubyte")):
+            self.data_X, self.data_y = self.load_mnist()
+            c_dim = self.data_X[0].shape[-1]
+        if c_dim is None:
+            c_dim = 1 if self.dataset == 'mnist' else 3
+        self.c_dim = c_dim
+        self.grayscale = (self.c_dim == 1)
+
+        self.build_model()
+
+    # ------------------------------------------------------------------------------------ build
+    def build_model(self):
+        if self.crop:
+            image_dims = [self.output_height, self.output_width, self.c_dim]
+        else:
+            image_dims = [self.input_height, self.input_width, self.c_dim]
+        self.image_dims = image_dims
+        dev = self.store.device
+        with V.use_store(self.store), torch.no_grad():
+            z = torch.zeros(self.batch_size, self.z_dim, device=dev)
+            y = torch.zeros(self.batch_size, self.y_dim, device=dev) if self.y_dim else None
+            inputs = torch.zeros([self.batch_size] + image_dims, device=dev)
+            # variable creation order of dcgan.py:107-108 / 113-114: generator, then discriminator
+            self.generator(z, y)
+            self.discriminator(inputs, y, reuse=False)
+            # building must not run the graph: undo the moving-average side effect of the dry run
+            for name, var in self.store.vars.items():
+                if name.endswith('moving_mean'):
+                    var.data.zero_()
+                elif name.endswith('moving_variance'):
+                    var.data.fill_(1.0)
+
+        t_vars = self.store.trainable_variables()
+        self.d_vars = [var for var in t_vars if 'd_' in var.name]      # dcgan.py:146-147
+        self.g_vars = [var for var in t_vars if 'g_' in var.name]
+        opts = self.opts
+        self.d_group = self.store.pack('d', self.d_vars)
+        self.g_group = self.store.pack('g', self.g_vars)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            for t in [self.d_group.values, self.g_group.values]:
+                dist.broadcast(t, src=0, group=self.process_group)
+        self.d_optim = AdamOptimizer(opts.lr, beta1=opts.beta1).attach(self.d_group)   # dcgan.py:154-157
+        self.g_optim = AdamOptimizer(opts.lr, beta1=opts.beta1).attach(self.g_group)
+        self.counter = 1
+
+    # ------------------------------------------------------------------------------------ networks
+    def discriminator(self, image, y=None, reuse=False):
+        """dcgan.py:322-351.  Returns (sigmoid(h), h) like the reference."""
+        with ops.variable_scope("discriminator") as scope:
+            if reuse:
+                scope.reuse_variables()
+            if not self.y_dim:
+                h0 = lrelu(conv2d(image, self.df_dim, name='d_h0_conv'))
+                h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu')
+                h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu')
+                h3 = self.d_bn3(conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu')
+                h4 = linear(h3.reshape(self.batch_size, -1), 1, 'd_h3_lin')
+                return _sigmoid_value(h4), h4
+            yb = y.reshape(self.batch_size, 1, 1, self.y_dim)
+            x = conv_cond_concat(image, yb)
+            h0 = lrelu(conv2d(x, self.c_dim + self.y_dim, name='d_h0_conv'))
+            h0 = conv_cond_concat(h0, yb)
+            h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv'), act='lrelu')
+            h1 = h1.reshape(self.batch_size, -1)
+            h1 = concat([h1, y], 1)
+            h2 = self.d_bn2(linear(h1, self.dfc_dim, 'd_h2_lin'), act='lrelu')
+            h2 = concat([h2, y], 1)
+            h3 = linear(h2, 1, 'd_h3_lin')
+            return _sigmoid_value(h3), h3
+
+    def generator(self, z, y=None, train=True):
+        """dcgan.py:353-410 (and, with train=False, the sampler of :412-462)."""
+        with ops.variable_scope("generator") as scope:
+            if not train:
+                scope.reuse_variables()
+            bs = self.batch_size
+            if not self.y_dim:
+                s_h, s_w = self.output_height, self.output_width
+                s_h2, s_w2 = conv_out_size_same(s_h, 2), conv_out_size_same(s_w, 2)
+                s_h4, s_w4 = conv_out_size_same(s_h2, 2), conv_out_size_same(s_w2, 2)
+                s_h8, s_w8 = conv_out_size_same(s_h4, 2), conv_out_size_same(s_w4, 2)
+                s_h16, s_w16 = conv_out_size_same(s_h8, 2), conv_out_size_same(s_w8, 2)
+                # project `z` and reshape
+                self.t_z_, self.h0_w, self.h0_b = linear(z, self.gf_dim * 8 * s_h16 * s_w16, 'g_h0_lin', with_w=True)
+                self.h0 = self.t_z_.reshape(-1, s_h16, s_w16, self.gf_dim * 8)
+                h0 = self.g_bn0(self.h0, train=train, act='relu')
+                self.h1, self.h1_w, self.h1_b = deconv2d(h0, [bs, s_h8, s_w8, self.gf_dim * 4], name='g_h1', with_w=True)
+                h1 = self.g_bn1(self.h1, train=train, act='relu')
+                h2, self.h2_w, self.h2_b = deconv2d(h1, [bs, s_h4, s_w4, self.gf_dim * 2], name='g_h2', with_w=True)
+                h2 = self.g_bn2(h2, train=train, act='relu')
+                h3, self.h3_w, self.h3_b = deconv2d(h2, [bs, s_h2, s_w2, self.gf_dim * 1], name='g_h3', with_w=True)
+                h3 = self.g_bn3(h3, train=train, act='relu')
+                h4, self.h4_w, self.h4_b = deconv2d(h3, [bs, s_h, s_w, self.c_dim], name='g_h4', with_w=True)
+                return ops.tanh(h4)
+            s_h, s_w = self.output_height, self.output_width
+            s_h2, s_h4 = int(s_h / 2), int(s_h / 4)
+            s_w2, s_w4 = int(s_w / 2), int(s_w / 4)
+            yb = y.reshape(bs, 1, 1, self.y_dim)
+            z = concat([z, y], 1)
+            h0 = self.g_bn0(linear(z, self.gfc_dim, 'g_h0_lin'), train=train, act='relu')
+            h0 = concat([h0, y], 1)
+            h1 = self.g_bn1(linear(h0, self.gf_dim * 2 * s_h4 * s_w4, 'g_h1_lin'), train=train, act='relu')
+            h1 = h1.reshape(bs, s_h4, s_w4, self.gf_dim * 2)
+            h1 = conv_cond_concat(h1, yb)
+            h2 = self.g_bn2(deconv2d(h1, [bs, s_h2, s_w2, self.gf_dim * 2], name='g_h2'), train=train, act='relu')
+            h2 = conv_cond_concat(h2, yb)
+            return ops.sigmoid(deconv2d(h2, [bs, s_h, s_w, self.c_dim], name='g_h3'))
+
+    def sampler(self, z, y=None):
+        """dcgan.py:412-462: the generator with batch-norm in inference mode."""
+        with V.use_store(self.store), torch.no_grad():
+            return self.generator(z, y, train=False)
+
+    # ------------------------------------------------------------------------------------ updates
+    def d_grads(self, images, z, y=None):
+        """Forward + backward of d_loss w.r.t. d_vars (the gradient half of minimize, dcgan.py:154-155):
+        leaves the local gradients in the d group's arena.  Returns (d_loss_real, d_loss_fake) as
+        1-element device tensors (d_loss is their sum, dcgan.py:139)."""
+        with V.use_store(self.store):
+            self.d_optim.begin()
+            with torch.no_grad():
+                G = self.generator(z, y)                       # gradients stop at d_vars: no G tape
+            _, D_logits = self.discriminator(images, y, reuse=False)
+            _, D_logits_ = self.discriminator(G, y, reuse=True)
+            d_loss_real = ops.sigmoid_cross_entropy_mean(D_logits, 1.0)      # dcgan.py:129-132
+            d_loss_fake = ops.sigmoid_cross_entropy_mean(D_logits_, 0.0)
+            ops.backward([d_loss_real, d_loss_fake])
+            self.d_optim.finish_grads()
+        return d_loss_real.detach(), d_loss_fake.detach()
+
+    def g_grads(self, z, y=None):
+        """Forward + backward of g_loss w.r.t. g_vars (through D, whose weights get no gradient)."""
+        with V.use_store(self.store):
+            self.g_optim.begin()
+            G = self.generator(z, y)
+            _, D_logits_ = self.discriminator(G, y, reuse=True)
+            g_loss = ops.sigmoid_cross_entropy_mean(D_logits_, 1.0)          # dcgan.py:133-134
+            ops.backward(g_loss)
+            self.g_optim.finish_grads()
+        return g_loss.detach()
+
+    def d_update(self, images, z, y=None):
+        """sess.run([d_optim, ...]) of dcgan.py:228-233 / 263-264."""
+        losses = self.d_grads(images, z, y)
+        self.d_optim.all_reduce(self.world_size, self.process_group)
+        self.d_optim.adam(self.world_size)
+        return losses
+
+    def g_update(self, z, y=None):
+        """sess.run([g_optim, ...]) of dcgan.py:237-247 / 268-275."""
+        g_loss = self.g_grads(z, y)
+        self.g_optim.all_reduce(self.world_size, self.process_group)
+        self.g_optim.adam(self.world_size)
+        return g_loss
+
+    def eval_losses(self, images, z, y=None):
+        """The three logging re-evaluations of dcgan.py:249-260 / 277-279: forward only, on the
+        post-update weights, each its own run (so each also moves the BN moving averages)."""
+        with V.use_store(self.store), torch.no_grad():
+            errD_fake = ops.sigmoid_cross_entropy_mean(self.discriminator(self.generator(z, y), y, reuse=True)[1], 0.0)
+            errD_real = ops.sigmoid_cross_entropy_mean(self.discriminator(images, y, reuse=True)[1], 1.0)
+            errG = ops.sigmoid_cross_entropy_mean(self.discriminator(self.generator(z, y), y, reuse=True)[1], 1.0)
+        return errD_fake, errD_real, errG
+
+    def train_iteration(self, images, z, y=None, log_evals=False):
+        """One iteration of the loop body dcgan.py:226-279."""
+        d_real, d_fake = self.d_update(images, z, y)
+        g1 = self.g_update(z, y)
+        # Run g_optim twice to make sure that d_loss does not go to zero (different from paper)
+        g2 = self.g_update(z, y)
+        out = {'d_loss_real': d_real, 'd_loss_fake': d_fake, 'g_loss_1': g1, 'g_loss_2': g2}
+        if log_evals:
+            f, r, g = self.eval_losses(images, z, y)
+            out.update(errD_fake=f, errD_real=r, errG=g)
+        return out
+
+    def iteration_runner(self, images, z, y=None, segmented=None):
+        """The loop body dcgan.py:226-275 as replayable HIP graphs over static input buffers.
+
+        One GPU: the whole iteration is one graph.  Data parallel: the iteration is cut at its three
+        gradient exchanges into four graphs (D backward | D Adam + G pass 1 | G Adam + G pass 2 |
+        G Adam) and the all-reduces of the flat gradient arenas are issued between them on the same
+        stream.  Returns run(images, z, y=None) -> the dict train_iteration returns."""
+        from .graph import CapturedIteration, model_state_restore, model_state_snapshot
+        optims = [self.d_optim, self.g_optim]
+        snap = lambda: model_state_snapshot(self.store, optims)
+        rest = lambda s: model_state_restore(self.store, optims, s)
+        static = [images.clone(), z.clone(), None if y is None else y.clone()]
+        ws, pg = self.world_size, self.process_group
+
+        def refresh(im, zz, yy):
+            for dst, src in zip(static, (im, zz, yy)):
+                if dst is not None and src is not dst:
+                    dst.copy_(src, non_blocking=True)
+
+        if segmented is None:
+            segmented = ws > 1
+        if not segmented:
+            whole = CapturedIteration(lambda a, b, c: self.train_iteration(a, b, c), static, snap, rest, share_inputs=True)
+
+            def run(im, zz, yy=None):
+                refresh(im, zz, yy)
+                return whole(*static)
+            return run
+
+        def seg2(a, b, c):
+            self.d_optim.adam(ws)
+            return self.g_grads(b, c)
+
+        def seg3(a, b, c):
+            self.g_optim.adam(ws)
+            return self.g_grads(b, c)
+
+        def seg4(a, b, c):
+            self.g_optim.adam(ws)
+        s1 = CapturedIteration(lambda a, b, c: self.d_grads(a, b, c), static, snap, rest, share_inputs=True)
+        s2 = CapturedIteration(seg2, static, snap, rest, share_inputs=True)
+        s3 = CapturedIteration(seg3, static, snap, rest, share_inputs=True)
+        s4 = CapturedIteration(seg4, static, snap, rest, share_inputs=True)
+
+        def run(im, zz, yy=None):
+            refresh(im, zz, yy)
+            d_real, d_fake = s1(*static)
+            self.d_optim.all_reduce(ws, pg)
+            g1 = s2(*static)
+            self.g_optim.all_reduce(ws, pg)
+            g2 = s3(*static)
+            self.g_optim.all_reduce(ws, pg)
+            s4(*static)
+            return {'d_loss_real': d_real, 'd_loss_fake': d_fake, 'g_loss_1': g1, 'g_loss_2': g2}
+        return run
+
+    # ------------------------------------------------------------------------------------ train loop
+    def train(self, data_X=None, data_y=None, max_iters=None):
+        """dcgan.py:151-320 for in-memory data ([N,H,W,C] float array in the network's input range
+        and, for the conditional model, one-hot labels)."""
+        opts = self.opts
+        if data_X is None:
+            data_X, data_y = self.data_X, self.data_y
+        if data_X is None:
+            raise RuntimeError("no training data: pass data_X (and data_y) or place MNIST under ./data/mnist")
+        dev = self.store.device
+        rng = np.random.RandomState(getattr(opts, 'seed', 0))
+        start_time = time.time()
+        could_load, checkpoint_counter = self.load(self.checkpoint_dir)
+        if could_load:
+            self.counter = checkpoint_counter
+            print(" [*] Load SUCCESS")
+        else:
+            print(" [!] Load failed...")
+        iters = 0
+        for epoch in range(opts.nEpochs):
+            batch_idxs = int(min(len(data_X), opts.train_size)) // opts.batch_size
+            for idx in range(0, batch_idxs):
+                batch_images = torch.from_numpy(
+                    np.asarray(data_X[idx * opts.batch_size:(idx + 1) * opts.batch_size], dtype=np.float32)).to(dev)
+                batch_labels = None
+                if self.y_dim:
+                    batch_labels = torch.from_numpy(
+                        np.asarray(data_y[idx * opts.batch_size:(idx + 1) * opts.batch_size], dtype=np.float32)).to(dev)
+                batch_z = torch.from_numpy(
+                    rng.uniform(-1, 1, [opts.batch_size, self.z_dim]).astype(np.float32)).to(dev)
+                log = (idx % self.print_every == 0)
+                out = self.train_iteration(batch_images, batch_z, batch_labels, log_evals=log)
+                self.counter += 1
+                if log:
+                    print("Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f"
+                          % (epoch, idx, batch_idxs, time.time() - start_time,
+                             float(out['errD_fake']) + float(out['errD_real']), float(out['errG'])))
+                if np.mod(self.counter, 500) == 2:
+                    self.save(opts.checkpoint_dir, self.counter)
+                iters += 1
+                if max_iters is not None and iters >= max_iters:
+                    return
+
+    # ------------------------------------------------------------------------------------ data
+    def load_mnist(self):
+        """dcgan.py:464-499: idx files under ./data/mnist, train+test concatenated, shuffled with
+        seed 547, scaled to [0,1], labels one-hot."""
+        data_dir = os.path.join("./data", self.dataset)
+
+        def read(name, offset, shape):
+            with open(os.path.join(data_dir, name), 'rb') as fd:
+                loaded = np.frombuffer(fd.read(), dtype=np.uint8)
+            return loaded[offset:].reshape(shape).astype(np.float64)
+        trX = read('train-images-idx3-ubyte', 16, (60000, 28, 28, 1))
+        trY = read('train-labels-idx1-ubyte', 8, (60000,))
+        teX = read('t10k-images-idx3-ubyte', 16, (10000, 28, 28, 1))
+        teY = read('t10k-labels-idx1-ubyte', 8, (10000,))
+        X = np.concatenate((trX, teX), axis=0)
+        y = np.concatenate((trY, teY), axis=0).astype(np.int64)
+        seed = 547
+        np.random.seed(seed)
+        np.random.shuffle(X)
+        np.random.seed(seed)
+        np.random.shuffle(y)
+        y_vec = np.zeros((len(y), self.y_dim), dtype=np.float64)
+        for i, label in enumerate(y):
+            y_vec[i, y[i]] = 1.0
+        return X / 255., y_vec
+
+    # ------------------------------------------------------------------------------------ checkpoints
+    @property
+    def model_dir(self):
+        """dcgan.py:501-503"""
+        return "{}_{}_{}_{}_{}".format(self.model, self.dataset, self.batch_size, self.output_height, self.output_width)
+
+    def save(self, checkpoint_dir, step):
+        """dcgan.py:505-514: <checkpoint_dir>/<model_dir>/DCGAN.model-<step> (an .npz of every named
+        variable, the Adam slots and step counts)."""
+        model_name = "DCGAN.model"
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        if not os.path.exists(checkpoint_dir):
+            os.makedirs(checkpoint_dir)
+        return save_checkpoint(self.store, {'d': self.d_optim, 'g': self.g_optim},
+                               os.path.join(checkpoint_dir, model_name), step)
+
+    def load(self, checkpoint_dir):
+        """dcgan.py:516-530: newest checkpoint of this model_dir; the step comes from the file name."""
+        print(" [*] Reading checkpoints...")
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        path = latest_checkpoint(checkpoint_dir)
+        if path:
+            ckpt_name = os.path.basename(path)
+            load_checkpoint(self.store, {'d': self.d_optim, 'g': self.g_optim}, path)
+            counter = int(next(re.finditer(r"(\d+)(?!.*\d)", ckpt_name[:-len('.npz')])).group(0))
+            print(" [*] Success to read {}".format(ckpt_name))
+            return True, counter
+        print(" [*] Failed to find a checkpoint")
+        return False, 0
+
+
+def _sigmoid_value(logits):
+    """tf.nn.sigmoid(h) returned next to the logits (dcgan.py:334,351); value only, no gradient."""
+    with torch.no_grad():
+        return ops.sigmoid(logits.detach())
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint files shared by the three models
+# ---------------------------------------------------------------------------------------------
+def save_checkpoint(store, optims, prefix, step):
+    arrays = {'var/' + n: a for n, a in store.state_dict().items()}
+    for key, opt in optims.items():
+        g = opt.group
+        arrays['adam/%s/m' % key] = g.m.cpu().numpy()
+        arrays['adam/%s/v' % key] = g.v.cpu().numpy()
+        arrays['adam/%s/step' % key] = opt.step_dev.cpu().numpy()
+    path = "%s-%d.npz" % (prefix, step)
+    np.savez(path, **arrays)
+    with open(os.path.join(os.path.dirname(path), 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+    return path
+
+
+def latest_checkpoint(checkpoint_dir):
+    index = os.path.join(checkpoint_dir, 'checkpoint')
+    if not os.path.exists(index):
+        return None
+    m = re.search(r'model_checkpoint_path: "(.*)"', open(index).read())
+    if not m:
+        return None
+    path = os.path.join(checkpoint_dir, m.group(1))
+    return path if os.path.exists(path) else None
+
+
+def load_checkpoint(store, optims, path):
+    data = np.load(path, allow_pickle=False)
+    store.load_state_dict({k[len('var/'):]: data[k] for k in data.files if k.startswith('var/')})
+    for key, opt in optims.items():
+        g = opt.group
+        g.m.copy_(torch.from_numpy(data['adam/%s/m' % key]).to(g.m.device))
+        g.v.copy_(torch.from_numpy(data['adam/%s/v' % key]).to(g.v.device))
+        opt.step_dev.copy_(torch.from_numpy(data['adam/%s/step' % key]).to(opt.step_dev.device))

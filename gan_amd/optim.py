@@ -34,13 +34,25 @@ class AdamOptimizer(object):
     def begin(self):
         self.group.begin_update()
 
-    def apply(self, world_size=1, process_group=None):
-        """Finish the update: zero-fill untouched gradient slots, all-reduce, fused Adam step."""
-        g = self.group
-        g.end_update()
-        if world_size > 1:
+    def finish_grads(self):
+        """End of the backward pass: gradient slots nothing wrote to are zero-filled."""
+        self.group.end_update()
+
+    def all_reduce(self, world_size=1, process_group=None):
+        """Sum the group's flat gradient arena over the ranks (one collective per update)."""
+        if world_size > 1 or process_group is not None:
             import torch.distributed as dist
-            dist.all_reduce(g.grads, op=dist.ReduceOp.SUM, group=process_group)
+            dist.all_reduce(self.group.grads, op=dist.ReduceOp.SUM, group=process_group)
+
+    def adam(self, world_size=1):
+        """The fused TF-Adam step; the 1/world_size gradient average is applied inside the kernel."""
+        g = self.group
         check(lib.gan_adam_tf_step(ptr(g.values), ptr(g.grads), ptr(g.m), ptr(g.v), g.numel, self.lr, self.beta1,
                                    self.beta2, self.eps, 1.0 / float(world_size), ptr(self.step_dev),
                                    ptr(self.lr_scratch), stream()))
+
+    def apply(self, world_size=1, process_group=None):
+        """Finish the update: zero-fill untouched gradient slots, all-reduce, fused Adam step."""
+        self.finish_grads()
+        self.all_reduce(world_size, process_group)
+        self.adam(world_size)

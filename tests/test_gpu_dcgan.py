@@ -1,0 +1,211 @@
+"""DCGAN on the GPU against the numpy oracle: identical seeded weights and inputs, per-update
+gradients, the 1 D + 2 G schedule, Adam bookkeeping, loss trajectories, HIP-graph replay."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import autodiff as A
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def make_opts(**kw):
+    d = dict(model='DCGAN', dataset='synthetic', batch_size=8, input_height=16, input_width=16, output_height=16,
+             output_width=16, y_dim=None, z_dim=10, gf_dim=8, df_dim=8, gfc_dim=32, dfc_dim=32, c_dim=3, lr=0.0002,
+             beta1=0.5, crop=True, nEpochs=1, train_size=1e8, print_every=1, checkpoint_dir='./checkpoint', seed=0)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def build_pair(opts, seed=11):
+    """An oracle model and a GPU model holding bit-identical weights."""
+    from gan_amd.dcgan import DCGAN
+    rng = np.random.default_rng(seed)
+    st = A.Store(seed=seed)
+    ref = nets.DCGAN(st, batch_size=opts.batch_size, output_height=opts.output_height, output_width=opts.output_width,
+                     c_dim=opts.c_dim, y_dim=opts.y_dim, z_dim=opts.z_dim, gf_dim=opts.gf_dim, df_dim=opts.df_dim,
+                     gfc_dim=opts.gfc_dim, dfc_dim=opts.dfc_dim, lr=opts.lr, beta1=opts.beta1)
+    shape = (opts.batch_size, opts.output_height, opts.output_width, opts.c_dim)
+    y0 = None if not opts.y_dim else np.zeros((opts.batch_size, opts.y_dim), np.float32)
+    ref.build(np.zeros(shape, np.float32), np.zeros((opts.batch_size, opts.z_dim), np.float32), y0)
+    # perturb the BN affine parameters and biases so that nothing is checked at a trivial value
+    for n in st.trainable:
+        if n.endswith(('gamma', 'beta', 'biases', 'bias')):
+            st.values[n] = (st.values[n] + rng.standard_normal(st.values[n].shape) * 0.1).astype(np.float32)
+    gpu = DCGAN(None, opts, load_data=False)
+    assert list(gpu.store.vars) == list(st.values), "variable names / creation order differ from the oracle"
+    gpu.store.load_state_dict(st.values)
+    return ref, gpu, rng
+
+
+def batch(opts, rng, lo=-1.0):
+    images = rng.uniform(lo, 1, (opts.batch_size, opts.output_height, opts.output_width, opts.c_dim)).astype(np.float32)
+    z = rng.uniform(-1, 1, (opts.batch_size, opts.z_dim)).astype(np.float32)
+    y = None
+    if opts.y_dim:
+        y = np.eye(opts.y_dim, dtype=np.float32)[rng.integers(0, opts.y_dim, opts.batch_size)]
+    return images, z, y
+
+
+def to_dev(*arrs):
+    return [None if a is None else torch.from_numpy(a).cuda() for a in arrs]
+
+
+def check_grad(name, got, ref, tol=2e-4):
+    """A bias that feeds a batch norm has an exactly-zero true gradient; both sides then hold only
+    rounding noise, which is compared against an absolute bound instead of relatively."""
+    from gpu_util import assert_close
+    if float(np.abs(ref).max()) < 1e-5:
+        assert float(np.abs(got).max()) < 1e-5, "grad %s should vanish" % name
+    else:
+        assert_close(got, ref, "grad " + name, tol=tol)
+
+
+def grads_by_name(group):
+    return {v.name: v.grad.detach().cpu().numpy() for v in group.variables}
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_update_gradients_match_oracle(cond):
+    from gpu_util import assert_close
+    opts = make_opts(y_dim=4, c_dim=1, output_height=12, output_width=12, input_height=12) if cond else make_opts()
+    ref, gpu, rng = build_pair(opts)
+    images, z, y = batch(opts, rng, lo=0.0 if cond else -1.0)
+    # oracle gradients of d_loss w.r.t. d_vars and g_loss w.r.t. g_vars at the same weights
+    before = {n: v.copy() for n, v in ref.st.values.items()}
+    tp = A.Tape(ref.st)
+    lr_, lf_ = ref.d_losses(tp, images, z, y)
+    tp.backward(A.add(tp, lr_, lf_))
+    d_ref = tp.grads(ref.d_vars)
+    di, dz, dy = to_dev(images, z, y)
+    d_real, d_fake = gpu.d_update(di, dz, dy)
+    torch.cuda.synchronize()
+    assert_close(d_real.cpu().numpy(), [float(lr_.v)], "d_loss_real")
+    assert_close(d_fake.cpu().numpy(), [float(lf_.v)], "d_loss_fake")
+    for name, g in grads_by_name(gpu.d_group).items():
+        check_grad(name, g, d_ref[name])
+    # after the Adam step the weights must equal the oracle's Adam step from the same gradients
+    ref.st.values.update(before)
+    for n in list(ref.st.values):           # moving averages moved during the oracle forward: reset
+        ref.st.values[n] = before[n]
+    ref.d_update(images, z, y)
+    for v in gpu.d_group.variables:
+        if float(np.abs(d_ref[v.name]).max()) < 1e-5:
+            continue        # Adam normalises pure rounding noise to a +-lr step: not comparable
+        assert_close(v.data.cpu().numpy(), ref.st.values[v.name], "post-Adam " + v.name, tol=1e-4)
+    for n, v in gpu.store.vars.items():
+        if 'moving_' in n:
+            # a moving mean near zero is compared on the scale of the matching standard deviation
+            assert_close(v.data.cpu().numpy(), ref.st.values[n], n, tol=1e-3)
+    assert gpu.d_optim.steps_taken == 1 and gpu.g_optim.steps_taken == 0
+    # G update from the now-identical state
+    gpu.store.load_state_dict(ref.st.values)
+    tp = A.Tape(ref.st)
+    yn = None if y is None else tp.const(y)
+    gl = A.sigmoid_ce_mean(tp, ref.discriminator(tp, ref.generator(tp, tp.const(z), yn), yn), 1.0)
+    tp.backward(gl)
+    g_ref = tp.grads(ref.g_vars)
+    g_loss = gpu.g_update(dz, dy)
+    torch.cuda.synchronize()
+    assert_close(g_loss.cpu().numpy(), [float(gl.v)], "g_loss")
+    for name, g in grads_by_name(gpu.g_group).items():
+        check_grad(name, g, g_ref[name])
+
+
+def test_schedule_and_loss_trajectory_200_steps():
+    """200 iterations of the reference schedule from identical weights, fresh batch every step.
+    Training amplifies rounding differences (Adam turns near-zero gradients into +-lr steps, relu
+    kinks flip), so the yardstick is the float64 oracle and the fp32 numpy oracle's own drift from it."""
+    opts = make_opts()
+    ref, gpu, rng = build_pair(opts, seed=5)
+    # a float64 copy of the oracle from the same weights: the yardstick for how far fp32 rounding
+    # alone moves this trajectory
+    st64 = A.Store(seed=5, dtype=np.float64)
+    ref64 = nets.DCGAN(st64, batch_size=opts.batch_size, output_height=opts.output_height,
+                       output_width=opts.output_width, c_dim=opts.c_dim, z_dim=opts.z_dim, gf_dim=opts.gf_dim,
+                       df_dim=opts.df_dim, lr=opts.lr, beta1=opts.beta1)
+    shape = (opts.batch_size, opts.output_height, opts.output_width, opts.c_dim)
+    ref64.build(np.zeros(shape), np.zeros((opts.batch_size, opts.z_dim)))
+    for n in st64.values:
+        st64.values[n] = ref.st.values[n].astype(np.float64)
+    dev_gpu = np.zeros(200)
+    dev_f32 = np.zeros(200)
+    for it in range(200):
+        images, z, y = batch(opts, rng)
+        truth = ref64.train_iteration(images.astype(np.float64), z.astype(np.float64))
+        r = ref.train_iteration(images, z, y)
+        out = gpu.train_iteration(*to_dev(images, z, y))
+        got = {'d_loss': float(out['d_loss_real']) + float(out['d_loss_fake']),
+               'g_loss_1': float(out['g_loss_1']), 'g_loss_2': float(out['g_loss_2'])}
+        assert np.isfinite(list(got.values())).all()
+        dev_gpu[it] = max(abs(got[k] - truth[k]) for k in got)
+        dev_f32[it] = max(abs(r[k] - truth[k]) for k in got)
+    print("max |loss - float64 oracle| over 20 / 200 steps: gpu %.3e / %.3e, float32 numpy oracle %.3e / %.3e"
+          % (dev_gpu[:20].max(), dev_gpu.max(), dev_f32[:20].max(), dev_f32.max()))
+    assert gpu.d_optim.steps_taken == 200 and gpu.g_optim.steps_taken == 400
+    # stated tolerance: absolute loss deviation from the float64 trajectory <= 5e-2 over 200 steps
+    # and <= 2e-2 over the first 20, and never worse than 4x what the fp32 numpy oracle itself shows
+    assert dev_gpu[:20].max() <= 2e-2
+    assert dev_gpu.max() <= 5e-2
+    assert dev_gpu.max() <= 4 * dev_f32.max() + 1e-3
+
+
+def test_logging_evals_and_sampler():
+    from gpu_util import assert_close
+    opts = make_opts()
+    ref, gpu, rng = build_pair(opts, seed=7)
+    images, z, y = batch(opts, rng)
+    r = ref.train_iteration(images, z, y, log_evals=True)
+    out = gpu.train_iteration(*to_dev(images, z, y), log_evals=True)
+    for k in ('errD_fake', 'errD_real', 'errG'):
+        assert abs(float(out[k]) - r[k]) <= 1e-4 * max(1.0, abs(r[k])), k
+    for n, v in gpu.store.vars.items():
+        if 'moving_' in n:
+            # a moving mean near zero is compared on the scale of the matching standard deviation
+            assert_close(v.data.cpu().numpy(), ref.st.values[n], n, tol=5e-3)   # three Adam steps in
+    s_ref = ref.sample(z)
+    s = gpu.sampler(torch.from_numpy(z).cuda())
+    assert_close(s.cpu().numpy(), s_ref, "sampler output", tol=5e-4)
+
+
+def test_hip_graph_replay_equals_eager():
+    from gan_amd.graph import CapturedIteration, model_state_restore, model_state_snapshot
+    opts = make_opts()
+    _, eager, rng = build_pair(opts, seed=9)
+    _, graphed, _ = build_pair(opts, seed=9)
+    batches = [to_dev(*batch(opts, rng)[:2]) for _ in range(4)]
+    optims = [graphed.d_optim, graphed.g_optim]
+    step = CapturedIteration(lambda im, z: graphed.train_iteration(im, z), batches[0],
+                             snapshot=lambda: model_state_snapshot(graphed.store, optims),
+                             restore=lambda s: model_state_restore(graphed.store, optims, s))
+    for im, z in batches:
+        e = eager.train_iteration(im, z)
+        g = step(im, z)
+        torch.cuda.synchronize()
+        for k in e:
+            assert float(e[k]) == float(g[k]), k
+    for name, v in eager.store.vars.items():
+        assert torch.equal(v.data, graphed.store.vars[name].data), name
+    assert graphed.d_optim.steps_taken == 4 and graphed.g_optim.steps_taken == 8
+
+
+def test_checkpoint_round_trip(tmp_path):
+    opts = make_opts(checkpoint_dir=str(tmp_path))
+    _, gpu, rng = build_pair(opts, seed=3)
+    im, z = to_dev(*batch(opts, rng)[:2])
+    gpu.train_iteration(im, z)
+    path = gpu.save(str(tmp_path), 7)
+    assert path.endswith("DCGAN_synthetic_8_16_16/DCGAN.model-7.npz")
+    ref_state = gpu.store.state_dict()
+    expect = gpu.train_iteration(im, z)
+    _, other, _ = build_pair(opts, seed=4)
+    ok, counter = other.load(str(tmp_path))
+    assert ok and counter == 7
+    for n, a in ref_state.items():
+        np.testing.assert_array_equal(other.store.vars[n].data.cpu().numpy(), a)
+    got = other.train_iteration(im, z)
+    for k in expect:
+        assert float(expect[k]) == float(got[k])      # Adam slots and step counts came back too
