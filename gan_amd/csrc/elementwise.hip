@@ -210,37 +210,74 @@ __global__ __launch_bounds__(1024) void loss_kernel(int kind, const float* __res
 }
 
 // ------------------------------------------------------------------ column sums (bias gradient)
-// partial[rb][c] then a fixed-order final pass.
+// partial[rb][c] per row block, then one wave per channel sums the partials (fixed shuffle tree).
+// float4 path (c % 4 == 0 and c/4 divides 256): thread = (row lane, 4-channel group).
+__global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                                long rows, int c, long rows_per_block) {
+    __shared__ float4 red[256];
+    const int c4 = c >> 2;
+    const int cg = threadIdx.x % c4, rl = threadIdx.x / c4, RL = 256 / c4;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const float4* xp = reinterpret_cast<const float4*>(x) + cg;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += RL) {
+        const float4 v = xp[r * c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < RL; ++j) {
+            const float4 v = red[cg + j * c4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(partial + (long)blockIdx.x * c)[cg] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                              long rows, int c, long rows_per_block) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int ch = blockIdx.x * 64 + tx;
-    const long r0 = (long)blockIdx.y * rows_per_block;
+    const int ch = blockIdx.y * 64 + tx;
+    const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.f;
     if (ch < c)
         for (long r = r0 + ty; r < r1; r += 4) s += x[r * c + ch];
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && ch < c) partial[(long)blockIdx.y * c + ch] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    if (ty == 0 && ch < c) partial[(long)blockIdx.x * c + ch] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int c, int rblocks,
-                                    int accumulate) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int c,
+                                                           int rblocks, int accumulate) {
+    const int ch = (blockIdx.x * 256 + threadIdx.x) >> 6;  // one wave per channel
+    const int lane = threadIdx.x & 63;
     if (ch >= c) return;
     float s = 0.f;
-    for (int rb = 0; rb < rblocks; ++rb) s += partial[(long)rb * c + ch];
-    out[ch] = (accumulate ? out[ch] : 0.f) + s;
+    for (int rb = lane; rb < rblocks; rb += 64) s += partial[(long)rb * c + ch];
+    s = wave_sum(s);
+    if (lane == 0) out[ch] = (accumulate ? out[ch] : 0.f) + s;
 }
 
+static bool colsum_vec4(int c) { return (c % 4 == 0) && (c / 4 <= 256) && (256 % (c / 4) == 0); }
+
 static void colsum_plan(long rows, int c, int* rblocks, long* rows_per_block) {
-    const int ctiles = (c + 63) / 64;
-    long target = 1024 / ctiles;
-    if (target < 1) target = 1;
-    long rb = (rows + 63) / 64;
-    if (rb > target) rb = target;
+    long rb;
+    if (colsum_vec4(c)) {
+        const int row_lanes = 256 / (c / 4);
+        rb = (rows + row_lanes * 4 - 1) / (row_lanes * 4);
+        if (rb > 1024) rb = 1024;
+    } else {
+        const int ctiles = (c + 63) / 64;
+        long target = 1024 / ctiles;
+        if (target < 1) target = 1;
+        rb = (rows + 63) / 64;
+        if (rb > target) rb = target;
+    }
     if (rb < 1) rb = 1;
     *rows_per_block = (rows + rb - 1) / rb;
     *rblocks = (int)((rows + *rows_per_block - 1) / *rows_per_block);
@@ -261,10 +298,13 @@ int colsum(const float* x, float* out, long rows, int c, int accumulate, void* w
     const size_t need = (size_t)rb * c * sizeof(float);
     GAN_CHECK_ARG(ws && ws_bytes >= need, "%s: workspace of %zu bytes needed for the bias gradient, %zu given", what, need,
                   ws_bytes);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((c + 63) / 64, rb), dim3(256), 0, st, x, static_cast<float*>(ws), rows,
-                       c, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws), out, c,
-                       rb, accumulate);
+    if (colsum_vec4(c))
+        hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(rb), dim3(256), 0, st, x, static_cast<float*>(ws), rows, c, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(rb, (c + 63) / 64), dim3(256), 0, st, x, static_cast<float*>(ws), rows,
+                           c, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, st, static_cast<const float*>(ws), out, c, rb,
+                       accumulate);
     return check_launch(what);
 }
 

@@ -18,6 +18,12 @@
 // and each wave accumulates TM x TN 32x32 MFMA tiles.  K can be split over blockIdx.z;
 // partial tiles then go to output-shaped slabs that a second kernel sums in fixed order
 // (deterministic, no float atomics).
+//
+// The gather index arithmetic is division free inside the k loop: k -> (tap, channel) and
+// pixel -> (image, row, column) use multiply-high by host-computed reciprocals, and every
+// global load is unconditional (masked lanes read element 0 and are zeroed by a select), so
+// the loop body is one basic block the compiler can interleave with the MFMAs.
+#include <cstdint>
 #include <cstdlib>
 
 #include "common.h"
@@ -30,12 +36,27 @@ enum { MODE_FPROP = 0, MODE_TPROP = 1, MODE_WGRAD = 2 };
 constexpr int BK = 16;
 constexpr int kMaxClasses = 4;
 
+// n / d for n*d < 2^32 by multiply-high with m = floor(2^32/d) + 1 (d >= 2); d == 1 is a copy.
+struct FastDiv {
+    unsigned d, m;
+};
+
+static FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d ? d : 1;
+    f.m = f.d > 1 ? (unsigned)((1ull << 32) / f.d) + 1u : 0u;
+    return f;
+}
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return f.d > 1 ? __umulhi(n, f.m) : n; }
+
 struct ClassInfo {
     int ph, pw;    // (q + pad) mod stride of this class's output pixels
     int khc, kwc;  // taps of this class per axis
     int hq0, wq0;  // first quotient index whose pixel is inside the image
     int hq, wq;    // quotient extents
     int M, K;
+    FastDiv d_kwc;
 };
 
 struct IgemmArgs {
@@ -49,27 +70,19 @@ struct IgemmArgs {
     long slab_elems;
     int accumulate;
     int ncls;
+    FastDiv d_cb, d_cs, d_kw, d_hsws, d_ws;
     ClassInfo cls[kMaxClasses];
 };
 
 template <int V>
-struct Vec;
-template <>
-struct Vec<4> {
-    using T = float4;
-};
-template <>
-struct Vec<1> {
-    using T = float;
-};
-
-template <int V>
-__device__ __forceinline__ void load_vec(float (&dst)[V], const float* p, bool ok) {
+__device__ __forceinline__ void load_vec(float (&dst)[V], const float* base, long off, bool ok) {
+    const float* p = base + (ok ? off : 0L);
     if constexpr (V == 4) {
-        float4 v = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        dst[0] = ok ? v.x : 0.f; dst[1] = ok ? v.y : 0.f; dst[2] = ok ? v.z : 0.f; dst[3] = ok ? v.w : 0.f;
     } else {
-        dst[0] = ok ? *p : 0.f;
+        const float v = *p;
+        dst[0] = ok ? v : 0.f;
     }
 }
 
@@ -113,6 +126,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int nkt = (K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nkt, kt0 + p.kt_per_split);
+    const int kend = min(K, kt1 * BK);  // this block's k range is [kt0*BK, kend)
 
     // ---------------------------------------------------------------- A loader set-up
     constexpr int A_CPR = A_TRANS ? BK / VA : BM / VA;  // chunks per tile row (k-row for direct)
@@ -124,7 +138,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int SH = (MODE == MODE_TPROP) ? g.hs : g.hb;
     const int SW = (MODE == MODE_TPROP) ? g.ws : g.wb;
     const int SC = (MODE == MODE_TPROP) ? g.cs : g.cb;
-    const int TW = (MODE == MODE_TPROP) ? cl.kwc : g.kw;  // taps per filter row in the k decode
+    const FastDiv dSC = (MODE == MODE_TPROP) ? p.d_cs : p.d_cb;
+    const FastDiv dTW = (MODE == MODE_TPROP) ? cl.d_kwc : p.d_kw;  // taps per filter row in the k decode
 
     int a_base[A_PASS], a_y0[A_PASS], a_x0[A_PASS];  // A_TRANS: per output-pixel row
     int a_kh = 0, a_kw = 0, a_c = 0;                 // WGRAD: this thread's (tap, channel)
@@ -171,34 +186,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     auto load_a = [&](int kt) {
         if constexpr (A_TRANS) {
             const int k = kt * BK + a_chunk * VA;
-            const bool kv = k < K;
+            const bool kv = k < kend;
             const unsigned uk = kv ? (unsigned)k : 0u;
-            const int tapc = uk / (unsigned)SC;
+            const int tapc = fdiv(uk, dSC);
             const int cc = uk - tapc * SC;
-            const int ta = tapc / TW, tb = tapc - ta * TW;
+            const int ta = fdiv(tapc, dTW);
+            const int tb = tapc - ta * (int)dTW.d;
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
                 const int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
                 const int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
                 const bool ok = kv && a_base[ps] >= 0 && (unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW;
                 const long off = ((long)(a_base[ps] + iy * SW + ix)) * SC + cc;
-                load_vec<VA>(a_reg[ps], p.a + (ok ? off : 0), ok);
+                load_vec<VA>(a_reg[ps], p.a, off, ok);
             }
         } else {
-            const int hw = g.hs * g.ws;
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
                 const int kr = a_r + ps * A_STEP;
                 const int k = kt * BK + kr;
-                const bool kv = (kr < BK) && (k < K) && a_mvalid;
+                const bool kv = (kr < BK) && (k < kend) && a_mvalid;
                 const unsigned uk = kv ? (unsigned)k : 0u;
-                const int img = uk / (unsigned)hw;
-                const int rem = uk - img * hw;
-                const int oy = rem / g.ws, ox = rem - oy * g.ws;
+                const int img = fdiv(uk, p.d_hsws);
+                const int rem = uk - img * (int)p.d_hsws.d;
+                const int oy = fdiv(rem, p.d_ws);
+                const int ox = rem - oy * g.ws;
                 const int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
                 const bool ok = kv && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
                 const long off = ((long)((img * g.hb + iy) * g.wb + ix)) * g.cb + a_c;
-                load_vec<VA>(a_reg[ps], p.a + (ok ? off : 0), ok);
+                load_vec<VA>(a_reg[ps], p.a, off, ok);
             }
         }
     };
@@ -207,11 +223,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         if constexpr (B_TRANS) {
             // w[tap][n][c]: contiguous along k = (class tap, c)
             const int k = kt * BK + b_chunk * VB;
-            const bool kv = k < K;
+            const bool kv = k < kend;
             const unsigned uk = kv ? (unsigned)k : 0u;
-            const int tapc = uk / (unsigned)g.cs;
+            const int tapc = fdiv(uk, p.d_cs);
             const int cc = uk - tapc * g.cs;
-            const int ta = tapc / cl.kwc, tb = tapc - ta * cl.kwc;
+            const int ta = fdiv(tapc, cl.d_kwc);
+            const int tb = tapc - ta * cl.kwc;
             const int wtap = (cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb);
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 const int n = n0 + nr;
                 const bool ok = kv && (nr < BN) && (n < N);
                 const long off = ((long)(wtap * g.cb + n)) * g.cs + cc;
-                load_vec<VB>(b_reg[ps], p.b + (ok ? off : 0), ok);
+                load_vec<VB>(b_reg[ps], p.b, off, ok);
             }
         } else {
             // row-major [K][N] (filter as [taps*cb][cs], or the small image as [pixels][cs])
@@ -228,9 +245,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const int kr = b_r + ps * B_STEP;
                 const int k = kt * BK + kr;
-                const bool ok = (kr < BK) && (k < K) && (n < N);
+                const bool ok = (kr < BK) && (k < kend) && (n < N);
                 const long off = (long)k * N + n;
-                load_vec<VB>(b_reg[ps], p.b + (ok ? off : 0), ok);
+                load_vec<VB>(b_reg[ps], p.b, off, ok);
             }
         }
     };
@@ -305,11 +322,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         __syncthreads();
         int buf = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
-            const bool more = kt + 1 < kt1;
-            if (more) {
-                load_a(kt + 1);
-                load_b(kt + 1);
-            }
+            // the loads for slice kt+1 are issued unconditionally (past the end they are masked off)
+            load_a(kt + 1);
+            load_b(kt + 1);
             const float* As = smem + buf * STAGE;
             const float* Bs = As + BK * LDA;
 #pragma unroll
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
-            if (more) store_tiles(buf ^ 1);
+            store_tiles(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
@@ -443,6 +458,14 @@ static int geom_check(const gan_conv_geom& g) {
     const long wel = (long)g.kh * g.kw * g.cb * g.cs;
     GAN_CHECK_ARG(big < (1L << 31) && small < (1L << 31) && wel < (1L << 31),
                   "conv geometry: tensors of 2^31 elements or more are not supported");
+    // exactness range of the multiply-high index decodes (n * d < 2^32)
+    const uint64_t lim = 1ull << 32;
+    const uint64_t taps = (uint64_t)g.kh * g.kw;
+    GAN_CHECK_ARG(taps * g.cb * g.cb < lim && taps * g.cs * g.cs < lim,
+                  "conv geometry: taps * channels^2 must stay below 2^32");
+    const uint64_t hw = (uint64_t)g.hs * g.ws;
+    GAN_CHECK_ARG((uint64_t)g.n * hw * hw < lim || (g.n == 1 && (hw - 1) * hw < lim),
+                  "conv geometry: batch * (small height * width)^2 must stay below 2^32");
     return 0;
 }
 
@@ -463,7 +486,8 @@ static void build_classes(const gan_conv_geom& g, IgemmArgs& a) {
             if (c.wq < 0) c.wq = 0;
             c.M = g.n * c.hq * c.wq;
             c.K = c.khc * c.kwc * g.cs;
-            if (c.kwc == 0) c.kwc = 1;  // keeps the k decode's division defined; K is 0 anyway
+            if (c.kwc == 0) c.kwc = 1;  // keeps the k decode defined; K is 0 anyway
+            c.d_kwc = make_fastdiv((unsigned)c.kwc);
             a.cls[a.ncls++] = c;
         }
 }
@@ -595,7 +619,12 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.a = a; r.b = b; r.out = out; r.bias = bias;
     r.accumulate = accumulate;
     r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1;
-    for (int i = 0; i < kMaxClasses; ++i) r.cls[i] = ClassInfo{0, 0, 1, 1, 0, 0, 0, 0, 0, 0};
+    r.d_cb = make_fastdiv((unsigned)g.cb);
+    r.d_cs = make_fastdiv((unsigned)g.cs);
+    r.d_kw = make_fastdiv((unsigned)g.kw);
+    r.d_hsws = make_fastdiv((unsigned)(g.hs * g.ws));
+    r.d_ws = make_fastdiv((unsigned)g.ws);
+    for (int i = 0; i < kMaxClasses; ++i) r.cls[i] = ClassInfo{0, 0, 1, 1, 0, 0, 0, 0, 0, 0, make_fastdiv(1)};
     if (mode == MODE_FPROP) {
         r.M = g.n * g.hs * g.ws; r.N = g.cs; r.K = g.kh * g.kw * g.cb;
     } else if (mode == MODE_WGRAD) {

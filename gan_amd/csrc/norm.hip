@@ -1,47 +1,106 @@
 // Batch / instance normalisation fused with the activation that follows it (gfx950).
 //
-// Every kernel here is bandwidth bound.  x is viewed as [groups][rows][c] with c contiguous;
-// one wave reads 64 consecutive channels of one row per load (256 B coalesced), four waves of a
-// block walk four rows at a time, and partial statistics are combined through LDS, then across
-// blocks by a small finalize kernel in a fixed order (deterministic, no atomics).
+// Every kernel here is bandwidth bound.  x is viewed as [groups][rows][c] with c contiguous.
+// Reductions over rows run in two launches: a partial kernel (many blocks, 16-byte loads, four
+// rows in flight per thread) and a finalize kernel in which ONE WAVE owns one (group, channel):
+// its 64 lanes stride over the block partials and merge them with a fixed shuffle tree, so the
+// result is deterministic and the serial chain is at most rblocks/64 long.
 //
-// Training forward: (1) per-block two-pass mean / sum of squared deviations over a row range
-// (the second pass re-reads a range that is still L1/L2 resident), (2) Chan-merge of the block
-// partials, moving-average update, (3) normalise + affine + activation (+ residual).
-// Backward: (1) per-block sums of dz and dz*xhat, (2) merge, dgamma/dbeta, (3) dx.
+// Training forward: (1) per-block shifted sums -> (mean, sum of squared deviations),
+// (2) Chan merge of the partials, moving-average update, (3) normalise + affine + activation
+// (+ residual).  Backward: (1) per-block sums of dz and dz*xhat, (2) merge, dgamma/dbeta, (3) dx.
 #include "common.h"
 
 namespace gan {
 
-constexpr int kChanTile = 64;  // channels per block (one wave-width)
-constexpr int kRowLanes = 4;   // waves per block, each on its own row
+constexpr int kChanTile = 64;  // generic path: channels per block (one wave-width)
+constexpr int kRowLanes = 4;   // generic path: waves per block, each on its own row
 
 struct BnShape {
     int groups, rows, c;
     int rblocks, rows_per_block;
+    int vec4;  // 1: float4 path (c % 4 == 0 and c/4 divides 256)
 };
+
+static bool vec4_ok(int c) { return (c % 4 == 0) && (c / 4 <= 256) && (256 % (c / 4) == 0); }
 
 static BnShape bn_shape(int groups, int rows, int c) {
     BnShape s;
     s.groups = groups; s.rows = rows; s.c = c;
-    const int ctiles = (c + kChanTile - 1) / kChanTile;
-    long target = 2048 / ((long)ctiles * groups);
-    if (target < 1) target = 1;
-    int rb = (rows + 31) / 32;  // at least 32 rows per block
-    if (rb > target) rb = (int)target;
+    s.vec4 = vec4_ok(c) ? 1 : 0;
+    long rb;
+    if (s.vec4) {
+        const int row_lanes = 256 / (c / 4);
+        rb = (rows + row_lanes * 4 - 1) / (row_lanes * 4);  // >= 4 rows per thread
+        long cap = 1024 / groups;
+        if (cap < 1) cap = 1;
+        if (rb > cap) rb = cap;
+    } else {
+        const int ctiles = (c + kChanTile - 1) / kChanTile;
+        long cap = 1024 / ((long)ctiles * groups);
+        if (cap < 1) cap = 1;
+        rb = (rows + 31) / 32;
+        if (rb > cap) rb = cap;
+    }
     if (rb < 1) rb = 1;
-    s.rows_per_block = (rows + rb - 1) / rb;
+    s.rows_per_block = (int)((rows + rb - 1) / rb);
     s.rblocks = (rows + s.rows_per_block - 1) / s.rows_per_block;
     return s;
 }
 
-// partial[(g*rblocks + rb)*c + ch] = {mean, m2} over the block's rows
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+// ---------------------------------------------------------------------------- forward statistics
+// partial[(g*rblocks + rb)*c + ch] = {mean, m2} over the block's rows.
+// float4 path: thread = (row lane, 4-channel group); sums are taken about the block's first row
+// (shifted data), which keeps the one-pass variance free of cancellation.
+__global__ __launch_bounds__(256) void bn_partial_stats_v4_kernel(const float* __restrict__ x, float2* __restrict__ partial,
+                                                                  BnShape s) {
+    __shared__ float4 red1[256];
+    __shared__ float4 red2[256];
+    const int c4 = s.c >> 2;
+    const int cg = threadIdx.x % c4, rl = threadIdx.x / c4, RL = 256 / c4;
+    const int rb = blockIdx.x, grp = blockIdx.y;
+    const int r0 = rb * s.rows_per_block;
+    const int r1 = min(s.rows, r0 + s.rows_per_block);
+    const float4* xp = reinterpret_cast<const float4*>(x + ((long)grp * s.rows) * s.c) + cg;
+    const float4 shift = xp[(long)r0 * c4];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const float4 d = f4_sub(xp[(long)r * c4], shift);
+        s1 = f4_add(s1, d);
+        s2 = f4_fma(d, d, s2);
+    }
+    red1[threadIdx.x] = s1;
+    red2[threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < RL; ++j) {
+            s1 = f4_add(s1, red1[cg + j * c4]);
+            s2 = f4_add(s2, red2[cg + j * c4]);
+        }
+        const float inv = 1.0f / (float)(r1 - r0);
+        float2* out = partial + ((long)grp * s.rblocks + rb) * s.c + cg * 4;
+        out[0] = make_float2(shift.x + s1.x * inv, s2.x - s1.x * s1.x * inv);
+        out[1] = make_float2(shift.y + s1.y * inv, s2.y - s1.y * s1.y * inv);
+        out[2] = make_float2(shift.z + s1.z * inv, s2.z - s1.z * s1.z * inv);
+        out[3] = make_float2(shift.w + s1.w * inv, s2.w - s1.w * s1.w * inv);
+    }
+}
+
+// generic path (any c): 64-channel tiles, two passes over a row range that stays cache resident
 __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float* __restrict__ x, float2* __restrict__ partial,
                                                                BnShape s) {
     __shared__ float red[kRowLanes][kChanTile];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int ch = blockIdx.x * kChanTile + tx;
-    const int rb = blockIdx.y, grp = blockIdx.z;
+    const int ch = blockIdx.z * kChanTile + tx;
+    const int rb = blockIdx.x, grp = blockIdx.y;
     const int r0 = rb * s.rows_per_block;
     const int r1 = min(s.rows, r0 + s.rows_per_block);
     const bool cv = ch < s.c;
@@ -66,32 +125,46 @@ __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const float* __re
         partial[((long)grp * s.rblocks + rb) * s.c + ch] = make_float2(mean, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
-// One thread per (group, channel): merge block partials, emit mean / rstd, update moving stats.
-__global__ void bn_finalize_stats_kernel(const float2* __restrict__ partial, float* __restrict__ save_mean,
-                                         float* __restrict__ save_rstd, float* __restrict__ moving_mean,
-                                         float* __restrict__ moving_var, BnShape s, float eps, float momentum,
-                                         int unbiased) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    const float nn = n + nb;
+    if (nn > 0.f) {
+        const float f = nb / nn;
+        const float delta = mb - mean;
+        mean += delta * f;
+        m2 += m2b + delta * delta * n * f;
+        n = nn;
+    }
+}
+
+// One wave per (group, channel).
+__global__ __launch_bounds__(256) void bn_finalize_stats_kernel(const float2* __restrict__ partial, float* __restrict__ save_mean,
+                                                                float* __restrict__ save_rstd, float* __restrict__ moving_mean,
+                                                                float* __restrict__ moving_var, BnShape s, float eps,
+                                                                float momentum, int unbiased) {
+    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 6;  // wave-uniform
+    const int lane = threadIdx.x & 63;
     if (idx >= s.groups * s.c) return;
     const int grp = idx / s.c, ch = idx - grp * s.c;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int rb = 0; rb < s.rblocks; ++rb) {
+    for (int rb = lane; rb < s.rblocks; rb += 64) {
         const float2 pr = partial[((long)grp * s.rblocks + rb) * s.c + ch];
         const int r0 = rb * s.rows_per_block;
-        const float nb = (float)(min(s.rows, r0 + s.rows_per_block) - r0);
-        const float delta = pr.x - mean;
-        const float nn = n + nb;
-        mean += delta * (nb / nn);
-        m2 += pr.y + delta * delta * (n * nb / nn);
-        n = nn;
+        chan_merge(n, mean, m2, (float)(min(s.rows, r0 + s.rows_per_block) - r0), pr.x, pr.y);
     }
-    const float var = m2 / n;
-    save_mean[idx] = mean;
-    save_rstd[idx] = 1.0f / sqrtf(var + eps);
-    if (moving_mean != nullptr) {
-        const float v = unbiased ? var * (n / fmaxf(n - 1.f, 1.f)) : var;
-        moving_mean[ch] = moving_mean[ch] * momentum + mean * (1.f - momentum);
-        moving_var[ch] = moving_var[ch] * momentum + v * (1.f - momentum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float nb = __shfl_down(n, off, 64), mb = __shfl_down(mean, off, 64), m2b = __shfl_down(m2, off, 64);
+        chan_merge(n, mean, m2, nb, mb, m2b);
+    }
+    if (lane == 0) {
+        const float var = m2 / n;
+        save_mean[idx] = mean;
+        save_rstd[idx] = 1.0f / sqrtf(var + eps);
+        if (moving_mean != nullptr) {
+            const float v = unbiased ? var * (n / fmaxf(n - 1.f, 1.f)) : var;
+            moving_mean[ch] = moving_mean[ch] * momentum + mean * (1.f - momentum);
+            moving_var[ch] = moving_var[ch] * momentum + v * (1.f - momentum);
+        }
     }
 }
 
@@ -102,16 +175,16 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ beta, const float* __restrict__ mean,
                                 const float* __restrict__ rstd_or_var, const float* __restrict__ residual,
                                 float* __restrict__ y, int groups, int rows, int c, float eps, int act, float act_param) {
-    const long total = (long)groups * rows * c;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long per_group = (long)rows * c;
+    const unsigned total = (unsigned)groups * rows * c;  // < 2^31 checked on the host
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned per_group = (unsigned)rows * c;
     if ((c & 3) == 0) {
-        for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride * 4) {
-            const int ch = (int)(i % c);
-            const int grp = (int)(i / per_group);
+        for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u; i < total; i += stride * 4u) {
+            const unsigned ch = i % (unsigned)c;
+            const unsigned gi = (i / per_group) * c + ch;
             const float4 xv = *reinterpret_cast<const float4*>(x + i);
-            const float4 mu = *reinterpret_cast<const float4*>(mean + grp * c + ch);
-            float4 rs = *reinterpret_cast<const float4*>(rstd_or_var + grp * c + ch);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + gi);
+            float4 rs = *reinterpret_cast<const float4*>(rstd_or_var + gi);
             if (EVAL) {
                 rs.x = 1.0f / sqrtf(rs.x + eps); rs.y = 1.0f / sqrtf(rs.y + eps);
                 rs.z = 1.0f / sqrtf(rs.z + eps); rs.w = 1.0f / sqrtf(rs.w + eps);
@@ -130,19 +203,74 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             *reinterpret_cast<float4*>(y + i) = o;
         }
     } else {
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-            const int ch = (int)(i % c);
-            const int grp = (int)(i / per_group);
-            float rs = rstd_or_var[grp * c + ch];
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const unsigned ch = i % (unsigned)c;
+            const unsigned gi = (i / per_group) * c + ch;
+            float rs = rstd_or_var[gi];
             if (EVAL) rs = 1.0f / sqrtf(rs + eps);
-            float o = apply_act((x[i] - mean[grp * c + ch]) * rs * gamma[ch] + beta[ch], act, act_param);
+            float o = apply_act((x[i] - mean[gi]) * rs * gamma[ch] + beta[ch], act, act_param);
             if (residual) o += residual[i];
             y[i] = o;
         }
     }
 }
 
+// ---------------------------------------------------------------------------- backward
+__device__ __forceinline__ float dz_of(float xv, float dyv, float mu, float rs, float ga, float be, int act,
+                                       float act_param, float& xhat) {
+    xhat = (xv - mu) * rs;
+    if (act == GAN_ACT_NONE) return dyv;
+    const float z = xhat * ga + be;
+    return dyv * act_grad(z, apply_act(z, act, act_param), act, act_param);
+}
+
 // partial[(g*rblocks+rb)*c + ch] = {sum dz, sum dz*xhat},  dz = dy * act'(z)
+__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                float2* __restrict__ partial, BnShape s, int act, float act_param) {
+    __shared__ float4 red1[256];
+    __shared__ float4 red2[256];
+    const int c4 = s.c >> 2;
+    const int cg = threadIdx.x % c4, rl = threadIdx.x / c4, RL = 256 / c4;
+    const int rb = blockIdx.x, grp = blockIdx.y;
+    const int r0 = rb * s.rows_per_block;
+    const int r1 = min(s.rows, r0 + s.rows_per_block);
+    const long base = ((long)grp * s.rows) * s.c;
+    const float4* xp = reinterpret_cast<const float4*>(x + base) + cg;
+    const float4* dp = reinterpret_cast<const float4*>(dy + base) + cg;
+    const float4 mu = reinterpret_cast<const float4*>(mean + grp * s.c)[cg];
+    const float4 rs = reinterpret_cast<const float4*>(rstd + grp * s.c)[cg];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[cg];
+    const float4 be = reinterpret_cast<const float4*>(beta)[cg];
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const float4 xv = xp[(long)r * c4], dv = dp[(long)r * c4];
+        float4 xh, dz;
+        dz.x = dz_of(xv.x, dv.x, mu.x, rs.x, ga.x, be.x, act, act_param, xh.x);
+        dz.y = dz_of(xv.y, dv.y, mu.y, rs.y, ga.y, be.y, act, act_param, xh.y);
+        dz.z = dz_of(xv.z, dv.z, mu.z, rs.z, ga.z, be.z, act, act_param, xh.z);
+        dz.w = dz_of(xv.w, dv.w, mu.w, rs.w, ga.w, be.w, act, act_param, xh.w);
+        s0 = f4_add(s0, dz);
+        s1 = f4_fma(dz, xh, s1);
+    }
+    red1[threadIdx.x] = s0;
+    red2[threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < RL; ++j) {
+            s0 = f4_add(s0, red1[cg + j * c4]);
+            s1 = f4_add(s1, red2[cg + j * c4]);
+        }
+        float2* out = partial + ((long)grp * s.rblocks + rb) * s.c + cg * 4;
+        out[0] = make_float2(s0.x, s1.x);
+        out[1] = make_float2(s0.y, s1.y);
+        out[2] = make_float2(s0.z, s1.z);
+        out[3] = make_float2(s0.w, s1.w);
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -150,8 +278,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     __shared__ float red0[kRowLanes][kChanTile];
     __shared__ float red1[kRowLanes][kChanTile];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int ch = blockIdx.x * kChanTile + tx;
-    const int rb = blockIdx.y, grp = blockIdx.z;
+    const int ch = blockIdx.z * kChanTile + tx;
+    const int rb = blockIdx.x, grp = blockIdx.y;
     const int r0 = rb * s.rows_per_block;
     const int r1 = min(s.rows, r0 + s.rows_per_block);
     const bool cv = ch < s.c;
@@ -162,12 +290,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const float ga = gamma[ch], be = beta[ch];
         for (int r = r0 + ty; r < r1; r += kRowLanes) {
             const long i = base + (long)r * s.c;
-            const float xhat = (x[i] - mu) * rs;
-            float dz = dy[i];
-            if (act != GAN_ACT_NONE) {
-                const float z = xhat * ga + be;
-                dz *= act_grad(z, apply_act(z, act, act_param), act, act_param);
-            }
+            float xhat;
+            const float dz = dz_of(x[i], dy[i], mu, rs, ga, be, act, act_param, xhat);
             s0 += dz;
             s1 += dz * xhat;
         }
@@ -181,26 +305,33 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                         red1[0][tx] + red1[1][tx] + red1[2][tx] + red1[3][tx]);
 }
 
-// sums[(g*c+ch)] = {sum dz, sum dz*xhat} per group; dgamma/dbeta = totals over groups.
-__global__ void bn_bwd_finalize_kernel(const float2* __restrict__ partial, float2* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, BnShape s,
-                                       int accumulate) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per channel: sums[(g*c+ch)] = {sum dz, sum dz*xhat} per group; dgamma/dbeta = totals.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ partial, float2* __restrict__ sums,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, BnShape s,
+                                                              int accumulate) {
+    const int ch = (blockIdx.x * 256 + threadIdx.x) >> 6;  // wave-uniform
+    const int lane = threadIdx.x & 63;
     if (ch >= s.c) return;
     float tg = 0.f, tb = 0.f;
     for (int grp = 0; grp < s.groups; ++grp) {
         float a0 = 0.f, a1 = 0.f;
-        for (int rb = 0; rb < s.rblocks; ++rb) {
+        for (int rb = lane; rb < s.rblocks; rb += 64) {
             const float2 pr = partial[((long)grp * s.rblocks + rb) * s.c + ch];
             a0 += pr.x;
             a1 += pr.y;
         }
-        sums[grp * s.c + ch] = make_float2(a0, a1);
-        tb += a0;
-        tg += a1;
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) {
+            sums[grp * s.c + ch] = make_float2(a0, a1);
+            tb += a0;
+            tg += a1;
+        }
     }
-    if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + tg;
-    if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + tb;
+    if (lane == 0) {
+        if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + tg;
+        if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + tb;
+    }
 }
 
 // dx = gamma*rstd*(dz - sum_dz/rows - xhat*sum_dz_xhat/rows)
@@ -209,22 +340,44 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float2* __restrict__ sums, float* __restrict__ dx, int groups, int rows,
                                     int c, int act, float act_param) {
-    const long total = (long)groups * rows * c;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long per_group = (long)rows * c;
+    const unsigned total = (unsigned)groups * rows * c;
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned per_group = (unsigned)rows * c;
     const float inv_rows = 1.0f / (float)rows;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int ch = (int)(i % c);
-        const int gi = (int)(i / per_group) * c + ch;
-        const float rs = rstd[gi], ga = gamma[ch];
-        const float xhat = (x[i] - mean[gi]) * rs;
-        float dz = dy[i];
-        if (act != GAN_ACT_NONE) {
-            const float z = xhat * ga + beta[ch];
-            dz *= act_grad(z, apply_act(z, act, act_param), act, act_param);
+    if ((c & 3) == 0) {
+        for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u; i < total; i += stride * 4u) {
+            const unsigned ch = i % (unsigned)c;
+            const unsigned gi = (i / per_group) * c + ch;
+            const float4 xv = *reinterpret_cast<const float4*>(x + i);
+            const float4 dv = *reinterpret_cast<const float4*>(dy + i);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + gi);
+            const float4 rs = *reinterpret_cast<const float4*>(rstd + gi);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+            const float4 be = *reinterpret_cast<const float4*>(beta + ch);
+            const float4 sa = *reinterpret_cast<const float4*>(sums + gi);       // {s0,s1} of ch, ch+1
+            const float4 sb = *reinterpret_cast<const float4*>(sums + gi + 2);   // {s0,s1} of ch+2, ch+3
+            float xh;
+            float4 o;
+            float dz = dz_of(xv.x, dv.x, mu.x, rs.x, ga.x, be.x, act, act_param, xh);
+            o.x = ga.x * rs.x * (dz - sa.x * inv_rows - xh * (sa.y * inv_rows));
+            dz = dz_of(xv.y, dv.y, mu.y, rs.y, ga.y, be.y, act, act_param, xh);
+            o.y = ga.y * rs.y * (dz - sa.z * inv_rows - xh * (sa.w * inv_rows));
+            dz = dz_of(xv.z, dv.z, mu.z, rs.z, ga.z, be.z, act, act_param, xh);
+            o.z = ga.z * rs.z * (dz - sb.x * inv_rows - xh * (sb.y * inv_rows));
+            dz = dz_of(xv.w, dv.w, mu.w, rs.w, ga.w, be.w, act, act_param, xh);
+            o.w = ga.w * rs.w * (dz - sb.z * inv_rows - xh * (sb.w * inv_rows));
+            *reinterpret_cast<float4*>(dx + i) = o;
         }
-        const float2 sm = sums[gi];
-        dx[i] = ga * rs * (dz - sm.x * inv_rows - xhat * (sm.y * inv_rows));
+    } else {
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const unsigned ch = i % (unsigned)c;
+            const unsigned gi = (i / per_group) * c + ch;
+            float xhat;
+            const float ga = gamma[ch], rs = rstd[gi];
+            const float dz = dz_of(x[i], dy[i], mean[gi], rs, ga, beta[ch], act, act_param, xhat);
+            const float2 sm = sums[gi];
+            dx[i] = ga * rs * (dz - sm.x * inv_rows - xhat * (sm.y * inv_rows));
+        }
     }
 }
 
@@ -251,6 +404,7 @@ extern "C" size_t gan_bn_workspace_bytes(int groups, int rows, int c) {
 
 static int bn_args_check(const char* what, int groups, int rows, int c, int act) {
     GAN_CHECK_ARG(groups > 0 && rows > 0 && c > 0, "%s: groups, rows and c must be positive", what);
+    GAN_CHECK_ARG(groups <= 65535, "%s: at most 65535 groups", what);
     GAN_CHECK_ARG((long)groups * rows * c < (1L << 31), "%s: tensors of 2^31 elements or more are not supported", what);
     GAN_CHECK_ARG(act >= GAN_ACT_NONE && act <= GAN_ACT_SIGMOID, "%s: unknown activation %d", what, act);
     return 0;
@@ -270,9 +424,12 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     const BnShape s = bn_shape(groups, rows, c);
     hipStream_t st = as_stream(stream);
     float2* partial = static_cast<float2*>(ws);
-    dim3 grid((c + kChanTile - 1) / kChanTile, s.rblocks, groups);
-    hipLaunchKernelGGL(bn_partial_stats_kernel, grid, dim3(256), 0, st, x, partial, s);
-    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((groups * c + 255) / 256), dim3(256), 0, st, partial, save_mean,
+    if (s.vec4)
+        hipLaunchKernelGGL(bn_partial_stats_v4_kernel, dim3(s.rblocks, groups), dim3(256), 0, st, x, partial, s);
+    else
+        hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(s.rblocks, groups, (c + kChanTile - 1) / kChanTile), dim3(256), 0,
+                           st, x, partial, s);
+    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((groups * c + 3) / 4), dim3(256), 0, st, partial, save_mean,
                        save_rstd, moving_mean, moving_var, s, eps, momentum, unbiased_moving_var);
     const long total = (long)groups * rows * c;
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for((c & 3) ? total : total / 4)), dim3(256), 0, st, x, gamma,
@@ -303,15 +460,18 @@ extern "C" int gan_bn_bwd(const float* x, const float* gamma, const float* beta,
     hipStream_t st = as_stream(stream);
     float2* partial = static_cast<float2*>(ws);
     float2* sums = partial + (size_t)groups * s.rblocks * c;
-    dim3 grid((c + kChanTile - 1) / kChanTile, s.rblocks, groups);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, partial, s,
-                       act, act_param);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, st, partial, sums, dgamma, dbeta, s,
+    if (s.vec4)
+        hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(s.rblocks, groups), dim3(256), 0, st, x, dy, gamma, beta, save_mean,
+                           save_rstd, partial, s, act, act_param);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.rblocks, groups, (c + kChanTile - 1) / kChanTile), dim3(256), 0, st, x,
+                           dy, gamma, beta, save_mean, save_rstd, partial, s, act, act_param);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, sums, dgamma, dbeta, s,
                        accumulate);
     if (dx != nullptr) {
         const long total = (long)groups * rows * c;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, gamma, beta, save_mean,
-                           save_rstd, sums, dx, groups, rows, c, act, act_param);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((c & 3) ? total : total / 4)), dim3(256), 0, st, x, dy, gamma,
+                           beta, save_mean, save_rstd, sums, dx, groups, rows, c, act, act_param);
     }
     return check_launch("gan_bn_bwd");
 }

@@ -346,10 +346,12 @@ def test_add_fill_concat_reflect(L):
                else np.concatenate([x, yv], axis=1))
         out = torch.empty(ref.shape, device='cuda')
         rows = int(np.prod(shape_x[:-1]))
-        L.check(L.lib.gan_concat_fwd(L.ptr(dev(x)), L.ptr(dev(yv)), L.ptr(out), rows, shape_x[-1], cy, rpb, L.stream()))
+        xd, yd = dev(x), dev(yv)         # named: a temporary would be freed (and its block reused) at once
+        L.check(L.lib.gan_concat_fwd(L.ptr(xd), L.ptr(yd), L.ptr(out), rows, shape_x[-1], cy, rpb, L.stream()))
         dout = RNG.standard_normal(ref.shape).astype(np.float32)
+        doutd = dev(dout)
         da, db = torch.empty(shape_x, device='cuda'), torch.empty((n, cy), device='cuda')
-        L.check(L.lib.gan_concat_bwd(L.ptr(dev(dout)), L.ptr(da), L.ptr(db), rows, shape_x[-1], cy, rpb, L.stream()))
+        L.check(L.lib.gan_concat_bwd(L.ptr(doutd), L.ptr(da), L.ptr(db), rows, shape_x[-1], cy, rpb, L.stream()))
         torch.cuda.synchronize()
         np.testing.assert_array_equal(host(out), ref)
         np.testing.assert_array_equal(host(da), dout[..., :shape_x[-1]])
@@ -360,10 +362,12 @@ def test_add_fill_concat_reflect(L):
         ref = T.reflect_pad(x, p)
         out = torch.empty(ref.shape, device='cuda')
         n, h, w, c = shape
-        L.check(L.lib.gan_reflect_pad_fwd(L.ptr(dev(x)), L.ptr(out), n, h, w, c, p, L.stream()))
+        xd = dev(x)
+        L.check(L.lib.gan_reflect_pad_fwd(L.ptr(xd), L.ptr(out), n, h, w, c, p, L.stream()))
         dyv = RNG.standard_normal(ref.shape).astype(np.float32)
+        dyd = dev(dyv)
         dx = torch.empty(shape, device='cuda')
-        L.check(L.lib.gan_reflect_pad_bwd(L.ptr(dev(dyv)), L.ptr(dx), n, h, w, c, p, L.stream()))
+        L.check(L.lib.gan_reflect_pad_bwd(L.ptr(dyd), L.ptr(dx), n, h, w, c, p, L.stream()))
         torch.cuda.synchronize()
         np.testing.assert_array_equal(host(out), ref)
         assert_close(host(dx), T.reflect_pad_backward(dyv.astype(np.float64), p), "reflect pad bwd")
@@ -388,7 +392,8 @@ def test_losses(L):
         assert_close(host(loss), [lref + 0.5 * l2], "mse accumulate")
         assert_close(host(g), 0.5 * g2, "mse grad")
         b = RNG.standard_normal(n).astype(np.float32)
-        L.check(L.lib.gan_l1_mean(L.ptr(xd), L.ptr(dev(b)), n, 10.0, 0, L.ptr(loss), L.ptr(g), L.stream()))
+        bd = dev(b)
+        L.check(L.lib.gan_l1_mean(L.ptr(xd), L.ptr(bd), n, 10.0, 0, L.ptr(loss), L.ptr(g), L.stream()))
         torch.cuda.synchronize()
         l1, g1 = T.l1_mean(x.astype(np.float64), b.astype(np.float64))
         assert_close(host(loss), [10 * l1], "l1 loss")
@@ -405,7 +410,8 @@ def test_adam_tf_steps(L):
     rt, rm, rv = theta.astype(np.float64), np.zeros(n), np.zeros(n)
     for t in range(1, 6):
         g = (RNG.standard_normal(n) * 0.01).astype(np.float32)
-        L.check(L.lib.gan_adam_tf_step(L.ptr(th), L.ptr(dev(g * 4)), L.ptr(m), L.ptr(v), n, 2e-4, 0.5, 0.999, 1e-8, 0.25,
+        gd = dev(g * 4)
+        L.check(L.lib.gan_adam_tf_step(L.ptr(th), L.ptr(gd), L.ptr(m), L.ptr(v), n, 2e-4, 0.5, 0.999, 1e-8, 0.25,
                                        L.ptr(step), L.ptr(lr_s), L.stream()))
         rt, rm, rv = T.adam_tf_step(rt, g.astype(np.float64), rm, rv, t, 2e-4, 0.5)
     torch.cuda.synchronize()
