@@ -48,7 +48,8 @@ static FastDiv make_fastdiv(unsigned d) {
     return f;
 }
 
-__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return f.d > 1 ? __umulhi(n, f.m) : n; }
+// d == 1 has m == 0: the product term vanishes and the (d == 1) term passes n through, branch free
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return __umulhi(n, f.m) + n * (unsigned)(f.d == 1u); }
 
 struct ClassInfo {
     int ph, pw;    // (q + pad) mod stride of this class's output pixels
@@ -74,15 +75,17 @@ struct IgemmArgs {
     ClassInfo cls[kMaxClasses];
 };
 
+// Raw gather load: masked-off lanes read element 0 of the tensor (always mapped); the zeroing
+// select happens when the registers are written to LDS one slice later, so nothing touches the
+// loaded registers -- and no vmcnt wait is needed -- while the loads are in flight.
 template <int V>
 __device__ __forceinline__ void load_vec(float (&dst)[V], const float* base, long off, bool ok) {
     const float* p = base + (ok ? off : 0L);
     if constexpr (V == 4) {
         const float4 v = *reinterpret_cast<const float4*>(p);
-        dst[0] = ok ? v.x : 0.f; dst[1] = ok ? v.y : 0.f; dst[2] = ok ? v.z : 0.f; dst[3] = ok ? v.w : 0.f;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     } else {
-        const float v = *p;
-        dst[0] = ok ? v : 0.f;
+        dst[0] = *p;
     }
 }
 
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int b_chunk = tid % B_CPR, b_r = tid / B_CPR;
 
     float a_reg[A_PASS][VA], b_reg[B_PASS][VB];
+    bool a_ok[A_PASS], b_ok[B_PASS];  // validity of the slice held in a_reg / b_reg
 
     auto load_a = [&](int kt) {
         if constexpr (A_TRANS) {
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 const bool ok = kv && a_base[ps] >= 0 && (unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW;
                 const long off = ((long)(a_base[ps] + iy * SW + ix)) * SC + cc;
                 load_vec<VA>(a_reg[ps], p.a, off, ok);
+                a_ok[ps] = ok;
             }
         } else {
 #pragma unroll
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 const bool ok = kv && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
                 const long off = ((long)((img * g.hb + iy) * g.wb + ix)) * g.cb + a_c;
                 load_vec<VA>(a_reg[ps], p.a, off, ok);
+                a_ok[ps] = ok;
             }
         }
     };
@@ -237,6 +243,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 const bool ok = kv && (nr < BN) && (n < N);
                 const long off = ((long)(wtap * g.cb + n)) * g.cs + cc;
                 load_vec<VB>(b_reg[ps], p.b, off, ok);
+                b_ok[ps] = ok;
             }
         } else {
             // row-major [K][N] (filter as [taps*cb][cs], or the small image as [pixels][cs])
@@ -248,55 +255,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 const bool ok = (kr < BK) && (k < kend) && (n < N);
                 const long off = (long)k * N + n;
                 load_vec<VB>(b_reg[ps], p.b, off, ok);
+                b_ok[ps] = ok;
             }
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_a = [&](int buf) {
         float* As = smem + buf * STAGE;
-        float* Bs = As + BK * LDA;
         if constexpr (A_TRANS) {
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
                 const int r = a_r + ps * A_STEP;
-                if (r < BM) {
+                if (A_EXT % A_STEP == 0 || r < BM) {
 #pragma unroll
-                    for (int v = 0; v < VA; ++v) As[(a_chunk * VA + v) * LDA + r] = a_reg[ps][v];
+                    for (int v = 0; v < VA; ++v) As[(a_chunk * VA + v) * LDA + r] = a_ok[ps] ? a_reg[ps][v] : 0.f;
                 }
             }
         } else {
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
                 const int kr = a_r + ps * A_STEP;
-                if (kr < BK) {
+                if (A_EXT % A_STEP == 0 || kr < BK) {
                     if constexpr (VA == 4) {
                         *reinterpret_cast<float4*>(&As[kr * LDA + a_chunk * 4]) =
-                            make_float4(a_reg[ps][0], a_reg[ps][1], a_reg[ps][2], a_reg[ps][3]);
+                            a_ok[ps] ? make_float4(a_reg[ps][0], a_reg[ps][1], a_reg[ps][2], a_reg[ps][3])
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {
-                        As[kr * LDA + a_chunk] = a_reg[ps][0];
+                        As[kr * LDA + a_chunk] = a_ok[ps] ? a_reg[ps][0] : 0.f;
                     }
                 }
             }
         }
+    };
+    auto store_b = [&](int buf) {
+        float* Bs = smem + buf * STAGE + BK * LDA;
         if constexpr (B_TRANS) {
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const int r = b_r + ps * B_STEP;
-                if (r < BN) {
+                if (B_EXT % B_STEP == 0 || r < BN) {
 #pragma unroll
-                    for (int v = 0; v < VB; ++v) Bs[(b_chunk * VB + v) * LDB + r] = b_reg[ps][v];
+                    for (int v = 0; v < VB; ++v) Bs[(b_chunk * VB + v) * LDB + r] = b_ok[ps] ? b_reg[ps][v] : 0.f;
                 }
             }
         } else {
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const int kr = b_r + ps * B_STEP;
-                if (kr < BK) {
+                if (B_EXT % B_STEP == 0 || kr < BK) {
                     if constexpr (VB == 4) {
                         *reinterpret_cast<float4*>(&Bs[kr * LDB + b_chunk * 4]) =
-                            make_float4(b_reg[ps][0], b_reg[ps][1], b_reg[ps][2], b_reg[ps][3]);
+                            b_ok[ps] ? make_float4(b_reg[ps][0], b_reg[ps][1], b_reg[ps][2], b_reg[ps][3])
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {
-                        Bs[kr * LDB + b_chunk] = b_reg[ps][0];
+                        Bs[kr * LDB + b_chunk] = b_ok[ps] ? b_reg[ps][0] : 0.f;
                     }
                 }
             }
@@ -315,32 +327,75 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int frag_b = wn * (BN / WN) + (lane & 31);
     const int kh2 = lane >> 5;
 
+    // One k-pair step: fragments of rows kk, kk+1 of the LDS images (lanes 0-31 take row kk,
+    // lanes 32-63 row kk+1: the A / B operand layout of the 32x32x2 MFMA).
+    auto frag = [&](const float* As, const float* Bs, int kk, float (&af)[TM], float (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = As[(kk + kh2) * LDA + frag_a + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + kh2) * LDB + frag_b + j * 32];
+    };
+    auto mma = [&](const float (&af)[TM], const float (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
     if (kt0 < kt1) {
+        // Software pipeline, one barrier per slice: while slice kt is multiplied out of LDS buffer
+        // `buf`, slice kt+1 (already in registers) is written to the other buffer and the global
+        // loads of slice kt+2 are issued, so they have a whole slice of MFMAs to land.  Inside a
+        // slice the fragments of step s+1 are read before the MFMAs of step s are issued, and the
+        // staging work is spread between the steps so that no gap between two MFMAs grows long.
         load_a(kt0);
         load_b(kt0);
-        store_tiles(0);
+        store_a(0);
+        store_b(0);
+        load_a(kt0 + 1);
+        load_b(kt0 + 1);
         __syncthreads();
         int buf = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
-            // the loads for slice kt+1 are issued unconditionally (past the end they are masked off)
-            load_a(kt + 1);
-            load_b(kt + 1);
             const float* As = smem + buf * STAGE;
             const float* Bs = As + BK * LDA;
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[(kk + kh2) * LDA + frag_a + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + kh2) * LDB + frag_b + j * 32];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-            store_tiles(buf ^ 1);
+            float af0[TM], bf0[TN], af1[TM], bf1[TN];
+            // The order below is pinned with sched_barrier: left alone, the scheduler undoes the
+            // fragment prefetch and parks the staging work where its latency is exposed.
+            frag(As, Bs, 0, af0, bf0);
+            frag(As, Bs, 2, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(As, Bs, 4, af0, bf0);
+            store_a(buf ^ 1);   // slice kt+1, loaded a whole slice ago (past the end: zeros, never read)
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(As, Bs, 6, af1, bf1);
+            store_b(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(As, Bs, 8, af0, bf0);
+            load_a(kt + 2);     // past the end: masked off
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(As, Bs, 10, af1, bf1);
+            load_b(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(As, Bs, 12, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(As, Bs, 14, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af0, bf0);
+            mma(af1, bf1);
             __syncthreads();
             buf ^= 1;
         }
@@ -371,6 +426,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
     float* dst = p.out + (p.splits > 1 ? (long)split * p.slab_elems : 0L);
     const bool direct = p.splits == 1;
+    const bool accum = direct && p.accumulate;
+    int ncol[TN];
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        bias_v[j] = (direct && p.bias != nullptr && ncol[j] < N) ? p.bias[ncol[j]] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -380,14 +443,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             if (off < 0) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-                if (n < N) {
-                    float v = acc[i][j][r];
-                    if (direct) {
-                        if (p.bias) v += p.bias[n];
-                        if (p.accumulate) v += dst[off + n];
-                    }
-                    dst[off + n] = v;
+                if (ncol[j] < N) {
+                    float v = acc[i][j][r] + bias_v[j];
+                    if (accum) v += dst[off + ncol[j]];
+                    dst[off + ncol[j]] = v;
                 }
             }
         }
@@ -425,6 +484,44 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
             if (accumulate) s += out[i];
             out[i] = s;
         }
+    }
+}
+
+// Same sum for many slabs over a small output (thin wgrad: hundreds of K splits): a block covers
+// 64 consecutive elements as 16 float4 columns x 16 split lanes; lane j adds slabs j, j+16, ...
+// and the 16 partial sums are combined through LDS in a fixed order.  Needs elems % 4 == 0.
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                const float* __restrict__ bias, long elems, int c,
+                                                                int splits, int accumulate) {
+    __shared__ float4 red[16][16];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i4 = (long)blockIdx.x * 16 + col;
+    const long n4 = elems >> 2;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n4) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += 16) {
+            const float4 t = reinterpret_cast<const float4*>(slabs + (long)k * elems)[i4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+    }
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && i4 < n4) {
+        for (int j = 1; j < 16; ++j) {
+            const float4 t = red[j][col];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (bias) {
+            const long e = i4 * 4;
+            s.x += bias[(int)(e % c)]; s.y += bias[(int)((e + 1) % c)];
+            s.z += bias[(int)((e + 2) % c)]; s.w += bias[(int)((e + 3) % c)];
+        }
+        if (accumulate) {
+            const float4 o = reinterpret_cast<const float4*>(out)[i4];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        reinterpret_cast<float4*>(out)[i4] = s;
     }
 }
 
@@ -530,7 +627,10 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
         splits = (int)(target / blocks);
         const int max_by_k = nkt / 8 > 0 ? nkt / 8 : 1;  // keep >= 8 k-slices (128 deep) per split
         if (splits > max_by_k) splits = max_by_k;
-        if (splits > 32) splits = 32;
+        // the slabs are written once and read once: keep them to a few tens of MB
+        const long max_by_bytes = (48L << 20) / (pl.out_elems * (long)sizeof(float) + 1);
+        if (splits > max_by_bytes) splits = (int)(max_by_bytes > 0 ? max_by_bytes : 1);
+        if (splits > 512) splits = 512;
         if (splits < 1) splits = 1;
     }
     if (const char* e = getenv("GAN_HIP_FORCE_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : 1;
@@ -592,7 +692,12 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         default: launch_cfg<MODE_WGRAD>(a, pl, grid, s); break;
     }
     if (int rc = check_launch(what)) return rc;
-    if (pl.splits > 1) {
+    if (pl.splits >= 16 && (pl.out_elems & 3) == 0) {
+        const long n4 = pl.out_elems >> 2;
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s,
+                           static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate);
+        if (int rc = check_launch(what)) return rc;
+    } else if (pl.splits > 1) {
         long work = (pl.out_elems + 3) / 4;
         int blocks = (int)((work + 255) / 256);
         if (blocks > 2048) blocks = 2048;
