@@ -1,0 +1,219 @@
+"""CycleGAN trainer on the HIP hot path, mirroring the reference's models/cyclegan.py: graph wiring
+of _build_model (:47-116), the four Adam optimisers (:123-130) and the five sequential runs of one
+training iteration (:159-180).  Image loading, sampling to disk and summaries (host side) are not
+part of the hot path; `train_iteration` takes the [N, s, s, 6] real_A|real_B tensor directly.
+"""
+from __future__ import division
+
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from . import variables as V
+from .cyclegan_module import (abs_criterion, discriminator, generator_resnet, generator_unet, mae_criterion,
+                              sce_criterion)
+from .dcgan import latest_checkpoint, load_checkpoint, save_checkpoint
+from .optim import AdamOptimizer
+
+
+class ImagePool(object):
+    """misc.py:249-267: history of generated images fed to the discriminators.  Entries are the
+    [fake_A, fake_B] pair of one iteration; `rand` / `randint` can be injected for reproducible tests."""
+
+    def __init__(self, maxsize=50, rand=None, randint=None):
+        self.maxsize = maxsize
+        self.num_img = 0
+        self.images = []
+        self.rand = rand or np.random.rand
+        self.randint = randint or (lambda n: int(np.random.rand() * n))
+
+    def __call__(self, image):
+        if self.maxsize == 0:
+            return image
+        if self.num_img < self.maxsize:
+            self.images.append(image)
+            self.num_img = self.num_img + 1
+            return image
+        if self.rand() > 0.5:
+            idx = self.randint(self.maxsize)
+            tmp = list(self.images[idx])
+            self.images[idx] = image
+            return tmp
+        else:
+            return image
+
+
+class CycleGAN(object):
+    def __init__(self, sess, opts, store=None, world_size=1, process_group=None):
+        self.sess = sess
+        self.batch_size = opts.batch_size
+        self.image_size = opts.fine_size
+        self.input_c_dim = opts.input_nc
+        self.output_c_dim = opts.output_nc
+        self.L1_lambda = opts.L1_lambda
+        self.dataset_dir = os.path.join(getattr(opts, 'data_dir', 'data'), opts.dataset)
+        self.dataset = opts.dataset
+
+        self.discriminator = discriminator
+        if opts.use_resnet:
+            self.generator = generator_resnet
+        else:
+            self.generator = generator_unet
+        if opts.use_lsgan:
+            self.criterionGAN = mae_criterion
+        else:
+            self.criterionGAN = sce_criterion
+
+        self.options = opts
+        self.options.image_size = opts.fine_size
+        self.options.output_c_dim = opts.output_nc
+
+        self.model_dir = "%s_%s" % (self.dataset, self.image_size)
+        self.world_size, self.process_group = world_size, process_group
+        self.store = store if store is not None else V.VariableStore(seed=getattr(opts, 'seed', 0))
+
+        self._build_model()
+        self.pool = ImagePool(opts.max_size)
+
+    def split(self, real_data):
+        """real_A = real_data[..., :input_c_dim], real_B = the next output_c_dim channels (:53-54)."""
+        a = real_data[:, :, :, :self.input_c_dim].contiguous()
+        b = real_data[:, :, :, self.input_c_dim:self.input_c_dim + self.output_c_dim].contiguous()
+        return a, b
+
+    def _build_model(self):
+        """Variable creation order of cyclegan.py:56-62; groups by name substring (:112-115)."""
+        dev = self.store.device
+        s = self.image_size
+        with V.use_store(self.store), torch.no_grad():
+            real_A = torch.zeros(self.batch_size, s, s, self.input_c_dim, device=dev)
+            real_B = torch.zeros(self.batch_size, s, s, self.output_c_dim, device=dev)
+            fake_B = self.generator(real_A, self.options, False, name="generatorA2B")
+            fake_A = self.generator(real_B, self.options, False, name="generatorB2A")
+            self.discriminator(fake_B, self.options, reuse=False, name="discriminatorB")
+            self.discriminator(fake_A, self.options, reuse=False, name="discriminatorA")
+            for name, var in self.store.vars.items():
+                if name.endswith('moving_mean'):
+                    var.data.zero_()
+                elif name.endswith('moving_variance'):
+                    var.data.fill_(1.0)
+        t_vars = self.store.trainable_variables()
+        self.db_vars = [var for var in t_vars if 'discriminatorB' in var.name]
+        self.da_vars = [var for var in t_vars if 'discriminatorA' in var.name]
+        self.g_vars_a2b = [var for var in t_vars if 'generatorA2B' in var.name]
+        self.g_vars_b2a = [var for var in t_vars if 'generatorB2A' in var.name]
+        opts = self.options
+        groups = {'da': self.da_vars, 'db': self.db_vars, 'g_a2b': self.g_vars_a2b, 'g_b2a': self.g_vars_b2a}
+        self.optims = {}
+        for key, vs in groups.items():
+            grp = self.store.pack(key, vs)
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.broadcast(grp.values, src=0, group=self.process_group)
+            self.optims[key] = AdamOptimizer(opts.lr, beta1=opts.beta1).attach(grp)     # cyclegan.py:123-130
+        self.da_optim, self.db_optim = self.optims['da'], self.optims['db']
+        self.g_a2b_optim, self.g_b2a_optim = self.optims['g_a2b'], self.optims['g_b2a']
+
+    # ------------------------------------------------------------------------------------ runs
+    def forward_fakes(self, real_data):
+        """sess.run([self.fake_A, self.fake_B]) (cyclegan.py:160-161)."""
+        real_A, real_B = self.split(real_data)
+        with V.use_store(self.store), torch.no_grad():
+            fake_B = self.generator(real_A, self.options, True, name="generatorA2B")
+            fake_A = self.generator(real_B, self.options, True, name="generatorB2A")
+        return fake_A, fake_B
+
+    def _finish(self, optim):
+        optim.finish_grads()
+        optim.all_reduce(self.world_size, self.process_group)
+        optim.adam(self.world_size)
+
+    def d_update(self, which, real, fake_sample):
+        """db_optim / da_optim (cyclegan.py:76-85, 164-166, 173-175):
+        loss = (criterionGAN(D(real), 1) + criterionGAN(D(fake_sample), 0)) / 2."""
+        optim = self.db_optim if which == 'B' else self.da_optim
+        name = "discriminator" + which
+        with V.use_store(self.store):
+            optim.begin()
+            l_real = self.criterionGAN(self.discriminator(real, self.options, reuse=True, name=name), 1.0, 0.5)
+            l_fake = self.criterionGAN(self.discriminator(fake_sample, self.options, reuse=True, name=name), 0.0, 0.5)
+            ops.backward([l_real, l_fake])
+            self._finish(optim)
+        return l_real.detach(), l_fake.detach()
+
+    def g_update(self, which, real_data):
+        """g_a2b_optim / g_b2a_optim (cyclegan.py:56-68, 169-170, 178-179): the GAN term of one
+        direction plus both L1 cycle terms, gradient w.r.t. that direction's generator only."""
+        real_A, real_B = self.split(real_data)
+        optim = self.g_a2b_optim if which == 'a2b' else self.g_b2a_optim
+        with V.use_store(self.store):
+            optim.begin()
+            fake_B = self.generator(real_A, self.options, True, name="generatorA2B")
+            fake_A_ = self.generator(fake_B, self.options, True, name="generatorB2A")
+            fake_A = self.generator(real_B, self.options, True, name="generatorB2A")
+            fake_B_ = self.generator(fake_A, self.options, True, name="generatorA2B")
+            if which == 'a2b':
+                gan = self.criterionGAN(self.discriminator(fake_B, self.options, reuse=True, name="discriminatorB"), 1.0)
+            else:
+                gan = self.criterionGAN(self.discriminator(fake_A, self.options, reuse=True, name="discriminatorA"), 1.0)
+            cyc_a = abs_criterion(real_A, fake_A_, self.L1_lambda)
+            cyc_b = abs_criterion(real_B, fake_B_, self.L1_lambda)
+            ops.backward([gan, cyc_a, cyc_b])
+            self._finish(optim)
+        return gan.detach(), cyc_a.detach(), cyc_b.detach()
+
+    def train_iteration(self, real_data):
+        """The loop body cyclegan.py:159-180.  Losses come back as 1-element device tensors."""
+        real_A, real_B = self.split(real_data)
+        # Forward G network
+        fake_A, fake_B = self.forward_fakes(real_data)
+        [fake_A, fake_B] = self.pool([fake_A, fake_B])
+        out = {}
+        # Update D network
+        r, f = self.d_update('B', real_B, fake_B)
+        out['db_loss_real'], out['db_loss_fake'] = r, f
+        # Update G network
+        out['g_a2b_gan'], out['g_a2b_cyc_a'], out['g_a2b_cyc_b'] = self.g_update('a2b', real_data)
+        # Update D network
+        r, f = self.d_update('A', real_A, fake_A)
+        out['da_loss_real'], out['da_loss_fake'] = r, f
+        # Update G network
+        out['g_b2a_gan'], out['g_b2a_cyc_a'], out['g_b2a_cyc_b'] = self.g_update('b2a', real_data)
+        return out
+
+    @staticmethod
+    def totals(out):
+        """db_loss, g_loss_a2b, da_loss, g_loss_b2a as floats (the four scalars the reference logs)."""
+        f = lambda k: float(out[k])
+        return {'db_loss': f('db_loss_real') + f('db_loss_fake'),
+                'g_loss_a2b': f('g_a2b_gan') + f('g_a2b_cyc_a') + f('g_a2b_cyc_b'),
+                'da_loss': f('da_loss_real') + f('da_loss_fake'),
+                'g_loss_b2a': f('g_b2a_gan') + f('g_b2a_cyc_a') + f('g_b2a_cyc_b')}
+
+    def test(self, images, which_direction='AtoB'):
+        """cyclegan.py:238-265 without the file I/O: translate a batch with one generator."""
+        if which_direction not in ('AtoB', 'BtoA'):
+            raise Exception('--which_direction must be AtoB or BtoA')
+        name = "generatorA2B" if which_direction == 'AtoB' else "generatorB2A"
+        with V.use_store(self.store), torch.no_grad():
+            return self.generator(images, self.options, True, name=name)
+
+    def save(self, checkpoint_dir, step):
+        """cyclegan.py:192-201"""
+        model_name = "CycleGAN.model"
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        if not os.path.exists(checkpoint_dir):
+            os.makedirs(checkpoint_dir)
+        return save_checkpoint(self.store, self.optims, os.path.join(checkpoint_dir, model_name), step)
+
+    def load(self, checkpoint_dir):
+        """cyclegan.py:203-214"""
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        print(" [*] Reading checkpoint from {}...".format(checkpoint_dir))
+        path = latest_checkpoint(checkpoint_dir)
+        if path:
+            load_checkpoint(self.store, self.optims, path)
+            return True
+        return False

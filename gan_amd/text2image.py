@@ -1,0 +1,259 @@
+"""Text-to-image GAN-CLS on the HIP hot path, mirroring the reference's models/text2image.py:
+generator (text2image.py:175-198), sampler (:148-172), discriminator (:201-222), the matching-aware
+losses of build_model (:73-128) and the per-batch schedule of train (:243-279): one D update over
+(real, right text) / (wrong image, right text) / (fake, right text), then two G updates.
+
+The data side of the reference (h5py / skimage loaders, :287-417) is host code outside the hot
+path; `train()` here takes in-memory arrays.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from . import variables as V
+from .dcgan import latest_checkpoint, load_checkpoint, save_checkpoint
+from .optim import AdamOptimizer
+
+
+class Text2Image(object):
+    '''
+    OPTIONS (text2image.py:16-25)
+    z_dim : Noise dimension 100
+    t_dim : Text feature dimension 256
+    image_size : Image Dimension 64
+    gf_dim : Number of conv in the first layer generator 64
+    df_dim : Number of conv in the first layer discriminator 64
+    caption_vector_length : Caption Vector Length 2400 (skipthought) / 1024 (DSSJE)
+    batch_size : Batch Size 64
+    '''
+
+    def __init__(self, sess, options, store=None, world_size=1, process_group=None):
+        self.textEncoder = options.textEncoder
+        self.sess = sess
+        self.model = getattr(options, 'model', 'Text2Image')
+        self.image_size = options.input_height
+        self.batch_size = options.batch_size
+        self.z_dim = options.z_dim
+        if options.caption_vector_length is not None:
+            self.caption_vector_length = options.caption_vector_length
+        else:
+            if options.textEncoder == 'skipthought':
+                self.caption_vector_length = 2400
+            elif options.textEncoder == 'DSSJE':
+                self.caption_vector_length = 1024
+            else:
+                raise ValueError('unknown text encoder')
+        if options.textEncoder == 'skipthought':
+            self.nCapsPerImage = 5
+        elif options.textEncoder == 'DSSJE':
+            self.nCapsPerImage = 10
+        else:
+            raise ValueError('unknown text encoder')
+        self.t_dim = options.t_dim
+        self.gf_dim = options.gf_dim
+        self.df_dim = options.df_dim
+        self.sample_dir = getattr(options, 'sample_dir', './samples')
+        self.checkpoint_dir = getattr(options, 'checkpoint_dir', './checkpoint')
+        self.nEpochs = options.nEpochs
+        self.dataset = options.dataset
+        self.lr = options.lr
+        self.beta1 = options.beta1
+        self.resume_model = getattr(options, 'resume_model', None)
+        self.data_dir = getattr(options, 'data_dir', 'data')
+        self.save_every_batch = getattr(options, 'save_every_batch', 50)
+        self.world_size, self.process_group = world_size, process_group
+        self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
+
+        self.g_bn0 = ops.batch_norm(name='g_bn0')
+        self.g_bn1 = ops.batch_norm(name='g_bn1')
+        self.g_bn2 = ops.batch_norm(name='g_bn2')
+        self.g_bn3 = ops.batch_norm(name='g_bn3')
+
+        self.d_bn1 = ops.batch_norm(name='d_bn1')
+        self.d_bn2 = ops.batch_norm(name='d_bn2')
+        self.d_bn3 = ops.batch_norm(name='d_bn3')
+        self.d_bn4 = ops.batch_norm(name='d_bn4')
+
+        self.build_model()
+
+    def build_model(self):
+        """Create the variables in the reference's order (generator, then discriminator:
+        text2image.py:80-82), split them by 'd_' / 'g_' (:94-96) and attach the two Adam optimisers
+        (:231-232)."""
+        dev = self.store.device
+        bs, s = self.batch_size, self.image_size
+        with V.use_store(self.store), torch.no_grad():
+            z = torch.zeros(bs, self.z_dim, device=dev)
+            cap = torch.zeros(bs, self.caption_vector_length, device=dev)
+            img = torch.zeros(bs, s, s, 3, device=dev)
+            self.generator(z, cap)
+            self.discriminator(img, cap)
+            for name, var in self.store.vars.items():
+                if name.endswith('moving_mean'):
+                    var.data.zero_()
+                elif name.endswith('moving_variance'):
+                    var.data.fill_(1.0)
+        t_vars = self.store.trainable_variables()
+        self.d_vars = [var for var in t_vars if 'd_' in var.name]
+        self.g_vars = [var for var in t_vars if 'g_' in var.name]
+        self.d_group = self.store.pack('d', self.d_vars)
+        self.g_group = self.store.pack('g', self.g_vars)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            for t in [self.d_group.values, self.g_group.values]:
+                dist.broadcast(t, src=0, group=self.process_group)
+        self.d_optim = AdamOptimizer(self.lr, beta1=self.beta1).attach(self.d_group)
+        self.g_optim = AdamOptimizer(self.lr, beta1=self.beta1).attach(self.g_group)
+
+    # Sample Images for a text embedding (text2image.py:148-172)
+    def sampler(self, t_z, t_text_embedding):
+        with V.use_store(self.store), torch.no_grad():
+            return self.generator(t_z, t_text_embedding, train=False)
+
+    # GENERATOR (text2image.py:175-198)
+    def generator(self, t_z, t_text_embedding, train=True):
+        with ops.variable_scope('generator') as scope:
+            if not train:
+                scope.reuse_variables()
+            s = self.image_size
+            s2, s4, s8, s16 = int(s / 2), int(s / 4), int(s / 8), int(s / 16)
+            bs = self.batch_size
+
+            reduced_text_embedding = ops.lrelu(ops.linear(t_text_embedding, self.t_dim, 'g_embedding'))
+            z_concat = ops.concat([t_z, reduced_text_embedding], 1)
+            z_ = ops.linear(z_concat, self.gf_dim * 8 * s16 * s16, 'g_h0_lin')
+            h0 = z_.reshape(-1, s16, s16, self.gf_dim * 8)
+            h0 = self.g_bn0(h0, train=train, act='relu')
+
+            h1 = ops.deconv2d(h0, [bs, s8, s8, self.gf_dim * 4], name='g_h1')
+            h1 = self.g_bn1(h1, train=train, act='relu')
+
+            h2 = ops.deconv2d(h1, [bs, s4, s4, self.gf_dim * 2], name='g_h2')
+            h2 = self.g_bn2(h2, train=train, act='relu')
+
+            h3 = ops.deconv2d(h2, [bs, s2, s2, self.gf_dim * 1], name='g_h3')
+            h3 = self.g_bn3(h3, train=train, act='relu')
+
+            h4 = ops.deconv2d(h3, [bs, s, s, 3], name='g_h4')
+
+            return ops.tanh(h4, scale=0.5, shift=0.5)      # tf.tanh(h4)/2. + 0.5
+
+    # DISCRIMINATOR (text2image.py:201-222)
+    def discriminator(self, image, t_text_embedding, reuse=False):
+        with ops.variable_scope("discriminator") as scope:
+            if reuse:
+                scope.reuse_variables()
+
+            h0 = ops.lrelu(ops.conv2d(image, self.df_dim, name='d_h0_conv'))                        # 32
+            h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu')          # 16
+            h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu')          # 8
+            h3 = self.d_bn3(ops.conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu')          # 4
+
+            # ADD TEXT EMBEDDING TO THE NETWORK: expand_dims x2 + tile [1,4,4,1] + concat on channels
+            reduced_text_embeddings = ops.lrelu(ops.linear(t_text_embedding, self.t_dim, 'd_embedding'))
+            h3_concat = ops.conv_cond_concat(h3, reduced_text_embeddings.reshape(self.batch_size, 1, 1, self.t_dim))
+            h3_new = self.d_bn4(ops.conv2d(h3_concat, self.df_dim * 8, 1, 1, 1, 1, name='d_h3_conv_new'), act='lrelu')  # 4
+
+            h4 = ops.linear(h3_new.reshape(self.batch_size, -1), 1, 'd_h3_lin')
+            with torch.no_grad():
+                prob = ops.sigmoid(h4.detach())
+            return prob, h4
+
+    # ---------------------------------------------------------------------------------- updates
+    def d_grads(self, real_image, wrong_image, real_caption, z):
+        """d_loss = d_loss1 + d_loss2 + d_loss3 (text2image.py:88-92) and its gradient w.r.t. d_vars."""
+        with V.use_store(self.store):
+            self.d_optim.begin()
+            with torch.no_grad():
+                fake_image = self.generator(z, real_caption)
+            _, real_logits = self.discriminator(real_image, real_caption)
+            _, wrong_logits = self.discriminator(wrong_image, real_caption, reuse=True)
+            _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True)
+            d_loss1 = ops.sigmoid_cross_entropy_mean(real_logits, 1.0)
+            d_loss2 = ops.sigmoid_cross_entropy_mean(wrong_logits, 0.0)
+            d_loss3 = ops.sigmoid_cross_entropy_mean(fake_logits, 0.0)
+            ops.backward([d_loss1, d_loss2, d_loss3])
+            self.d_optim.finish_grads()
+        return d_loss1.detach(), d_loss2.detach(), d_loss3.detach(), fake_image
+
+    def g_grads(self, real_caption, z):
+        """g_loss (text2image.py:86) and its gradient w.r.t. g_vars."""
+        with V.use_store(self.store):
+            self.g_optim.begin()
+            fake_image = self.generator(z, real_caption)
+            _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True)
+            g_loss = ops.sigmoid_cross_entropy_mean(fake_logits, 1.0)
+            ops.backward(g_loss)
+            self.g_optim.finish_grads()
+        return g_loss.detach(), fake_image.detach()
+
+    def d_update(self, real_image, wrong_image, real_caption, z):
+        out = self.d_grads(real_image, wrong_image, real_caption, z)
+        self.d_optim.all_reduce(self.world_size, self.process_group)
+        self.d_optim.adam(self.world_size)
+        return out
+
+    def g_update(self, real_caption, z):
+        out = self.g_grads(real_caption, z)
+        self.g_optim.all_reduce(self.world_size, self.process_group)
+        self.g_optim.adam(self.world_size)
+        return out
+
+    def train_iteration(self, real_image, wrong_image, real_caption, z):
+        """One batch of text2image.py:249-276: DISCR UPDATE, GEN UPDATE, GEN UPDATE TWICE."""
+        d1, d2, d3, _ = self.d_update(real_image, wrong_image, real_caption, z)
+        g1, _ = self.g_update(real_caption, z)
+        g2, gen = self.g_update(real_caption, z)
+        return {'d_loss1': d1, 'd_loss2': d2, 'd_loss3': d3, 'g_loss_1': g1, 'g_loss_2': g2, 'generator': gen}
+
+    def train(self, images, captions, max_iters=None, seed=0):
+        """text2image.py:224-285 for in-memory data: images [N,s,s,3] floats in [0,1], captions
+        [N, caption_vector_length].  The wrong image of a sample is a random other image
+        (get_training_batch, :389-397)."""
+        dev = self.store.device
+        rng = np.random.RandomState(seed)
+        n = len(images)
+        iters = 0
+        for i in range(self.nEpochs):
+            batch_no = 0
+            while (batch_no + 1) * self.batch_size <= n:
+                sl = slice(batch_no * self.batch_size, (batch_no + 1) * self.batch_size)
+                real = torch.from_numpy(np.asarray(images[sl], dtype=np.float32)).to(dev)
+                wrong = torch.from_numpy(np.asarray(images[rng.randint(0, n, self.batch_size)], dtype=np.float32)).to(dev)
+                cap = torch.from_numpy(np.asarray(captions[sl], dtype=np.float32)).to(dev)
+                z = torch.from_numpy(rng.uniform(-1, 1, [self.batch_size, self.z_dim]).astype(np.float32)).to(dev)
+                out = self.train_iteration(real, wrong, cap, z)
+                d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
+                print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
+                    i, batch_no, n // self.batch_size, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
+                batch_no += 1
+                if (batch_no % self.save_every_batch) == 0:
+                    self.save(self.checkpoint_dir, batch_no)
+                iters += 1
+                if max_iters is not None and iters >= max_iters:
+                    return
+            if i % 5 == 0:
+                self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))
+
+    @property
+    def model_dir(self):
+        """text2image.py:419-421"""
+        return "{}_{}_{}_{}".format(self.model, self.dataset, self.batch_size, self.image_size)
+
+    def save(self, checkpoint_dir, step, note=''):
+        """text2image.py:330-341: <checkpoint_dir>/<model_dir>/<model>.model[_note]-<step>"""
+        model_name = self.model + ".model" + (('_' + note) if note else '')
+        checkpoint_dir = os.path.join(checkpoint_dir, self.model_dir)
+        if not os.path.exists(checkpoint_dir):
+            os.makedirs(checkpoint_dir)
+        return save_checkpoint(self.store, {'d': self.d_optim, 'g': self.g_optim},
+                               os.path.join(checkpoint_dir, model_name), step)
+
+    def load(self, checkpoint_dir):
+        path = latest_checkpoint(os.path.join(checkpoint_dir, self.model_dir))
+        if not path:
+            return False
+        load_checkpoint(self.store, {'d': self.d_optim, 'g': self.g_optim}, path)
+        return True
