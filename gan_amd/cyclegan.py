@@ -110,8 +110,7 @@ class CycleGAN(object):
         for key, vs in groups.items():
             grp = self.store.pack(key, vs)
             if self.world_size > 1:
-                import torch.distributed as dist
-                dist.broadcast(grp.values, src=0, group=self.process_group)
+                grp.broadcast(self.process_group)
             self.optims[key] = AdamOptimizer(opts.lr, beta1=opts.beta1).attach(grp)     # cyclegan.py:123-130
         self.da_optim, self.db_optim = self.optims['da'], self.optims['db']
         self.g_a2b_optim, self.g_b2a_optim = self.optims['g_a2b'], self.optims['g_b2a']

@@ -42,7 +42,16 @@ class AdamOptimizer(object):
         """Sum the group's flat gradient arena over the ranks (one collective per update)."""
         if world_size > 1 or process_group is not None:
             import torch.distributed as dist
-            dist.all_reduce(self.group.grads, op=dist.ReduceOp.SUM, group=process_group)
+            grads = self.group.grads
+            if grads.is_cuda and dist.get_backend(process_group) == "gloo":
+                # gloo (CPU rigs and rehearsals with several ranks on one GPU) moves host memory:
+                # stage the arena through the host explicitly instead of relying on gloo's own
+                # device-tensor path, which was seen to stall behind a replayed HIP graph
+                host = grads.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+                grads.copy_(host)
+            else:
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=process_group)
 
     def adam(self, world_size=1):
         """The fused TF-Adam step; the 1/world_size gradient average is applied inside the kernel."""

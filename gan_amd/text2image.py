@@ -101,9 +101,8 @@ class Text2Image(object):
         self.d_group = self.store.pack('d', self.d_vars)
         self.g_group = self.store.pack('g', self.g_vars)
         if self.world_size > 1:
-            import torch.distributed as dist
-            for t in [self.d_group.values, self.g_group.values]:
-                dist.broadcast(t, src=0, group=self.process_group)
+            self.d_group.broadcast(self.process_group)
+            self.g_group.broadcast(self.process_group)
         self.d_optim = AdamOptimizer(self.lr, beta1=self.beta1).attach(self.d_group)
         self.g_optim = AdamOptimizer(self.lr, beta1=self.beta1).attach(self.g_group)
 

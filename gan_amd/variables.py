@@ -72,6 +72,16 @@ class Group(object):
             var.group = self
         self.offsets = offs
 
+    def broadcast(self, process_group=None, src=0):
+        """Data parallel start-up: every rank takes rank `src`'s values (one collective per group)."""
+        import torch.distributed as dist
+        if self.values.is_cuda and dist.get_backend(process_group) == "gloo":
+            host = self.values.cpu()            # gloo moves host memory (see AdamOptimizer.all_reduce)
+            dist.broadcast(host, src=src, group=process_group)
+            self.values.copy_(host)
+        else:
+            dist.broadcast(self.values, src=src, group=process_group)
+
     def begin_update(self):
         for v in self.variables:
             v.wants_grad = True

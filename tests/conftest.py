@@ -16,7 +16,7 @@ def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible, so a plain
     `pytest tests/` works on a CPU-only container."""
     import torch
-    if torch.cuda.is_available():
+    if torch.cuda.device_count() > 0:       # counting devices does not initialise the GPU runtime
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:

@@ -1,0 +1,198 @@
+"""Data parallelism: world_size-2 jobs, one process per rank, launched the way torch.distributed.run
+launches bench.py (RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment).
+
+The CPU test covers the host protocol (arena broadcast, one summing all-reduce per optimiser group).
+The GPU test runs the real DCGAN iteration with both ranks on the one visible device over gloo and
+checks it against two oracle replicas that exchange averaged gradients.  This module sorts first so
+that the rank processes are started before the pytest process itself has touched the GPU."""
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from oracle import autodiff as A
+from oracle import nets
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def launch(mode, out, world=2, timeout=600):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs, logs = [], []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
+        logs.append(open(os.path.join(str(out), "rank%d.log" % rank), "wb"))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "dp_worker.py"), mode, str(out)], env=env,
+                                      stdout=logs[-1], stderr=subprocess.STDOUT))
+    t0 = time.time()
+    beat = t0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break                               # a rank died: its peers would wait for it forever
+            if time.time() - t0 > timeout:
+                break
+            if time.time() - beat > 30:             # a sign of life past pytest's capture for long jobs
+                beat = time.time()
+                sys.__stderr__.write("[dp %s job: ranks running for %d s]\n" % (mode, beat - t0))
+                sys.__stderr__.flush()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for f in logs:
+            f.close()
+    for rank, p in enumerate(procs):
+        with open(os.path.join(str(out), "rank%d.log" % rank), "rb") as f:
+            log = f.read().decode(errors="replace")
+        assert p.returncode == 0, "rank %d exited with %s:\n%s" % (rank, p.returncode, log[-4000:])
+    return [np.load(os.path.join(str(out), "rank%d.npz" % r)) for r in range(world)]
+
+
+def test_gloo_broadcast_and_gradient_allreduce(tmp_path):
+    r0, r1 = launch("cpu", tmp_path)
+    # ranks were seeded differently: before the broadcast their arenas differ, after it rank 1 holds rank 0's
+    assert not np.array_equal(r0["values_before"], r1["values_before"])
+    np.testing.assert_array_equal(r0["values_after"], r0["values_before"])
+    np.testing.assert_array_equal(r1["values_after"], r0["values_before"])
+    # one summing all-reduce over the flat arena: every variable's slot holds g0 + g1 on both ranks,
+    # and the alignment gaps between the slots stay zero
+    names = [k[len("local/"):] for k in r0.files if k.startswith("local/")]
+    assert len(names) == 4                      # w, biases, beta, gamma -- the moving average is not trained
+    total = 0.0
+    for n in names:
+        want = r0["local/" + n] + r1["local/" + n]
+        np.testing.assert_array_equal(r0["reduced/" + n], want)
+        np.testing.assert_array_equal(r1["reduced/" + n], want)
+        total += float(np.abs(want).sum())
+    assert abs(float(np.abs(r0["grads_flat"]).sum()) - total) <= 1e-3 * total
+    assert int(r0["numel"][0]) % 64 == 0 and int(r0["moving_in_group"][0]) == 0
+
+
+def test_adam_receives_the_world_average_scale(monkeypatch):
+    """The 1/world_size average is applied by the Adam kernel's gradient scale argument."""
+    import torch
+    from gan_amd import _lib, optim, variables as V
+    st = V.VariableStore(device='cpu', seed=0)
+    st.get_variable('d_w', [4], V.constant_initializer(1.0))
+    opt = optim.AdamOptimizer(2e-4, beta1=0.5).attach(st.pack('d', st.select('d_')))
+    seen = {}
+
+    def fake_adam(values, grads, m, v, n, lr, b1, b2, eps, scale, step, scratch, stream):
+        seen.update(n=n, lr=lr, b1=b1, scale=scale)
+        return 0
+    monkeypatch.setattr(optim.lib, "gan_adam_tf_step", fake_adam)
+    monkeypatch.setattr(optim, "ptr", lambda t: None)
+    monkeypatch.setattr(optim, "stream", lambda: None)
+    opt.adam(8)
+    assert seen["scale"] == 0.125 and seen["b1"] == 0.5 and abs(seen["lr"] - 2e-4) < 1e-12
+    assert isinstance(opt.group.grads, torch.Tensor) and _lib is not None
+
+
+@pytest.mark.gpu
+def test_dcgan_data_parallel_two_ranks_match_oracle(tmp_path):
+    from gpu_util import assert_close, is_noise_grad
+    from test_gpu_dcgan import make_opts
+    opts = make_opts()
+    iters, world = 3, 2
+    rng = np.random.default_rng(17)
+
+    def replica():
+        st = A.Store(seed=17)
+        net = nets.DCGAN(st, batch_size=opts.batch_size, output_height=opts.output_height,
+                         output_width=opts.output_width, c_dim=opts.c_dim, z_dim=opts.z_dim, gf_dim=opts.gf_dim,
+                         df_dim=opts.df_dim, lr=opts.lr, beta1=opts.beta1)
+        shape = (opts.batch_size, opts.output_height, opts.output_width, opts.c_dim)
+        net.build(np.zeros(shape, np.float32), np.zeros((opts.batch_size, opts.z_dim), np.float32))
+        return net
+    reps = [replica() for _ in range(world)]
+    for n in reps[0].st.trainable:
+        if n.endswith(('gamma', 'beta', 'biases', 'bias')):
+            reps[0].st.values[n] = (reps[0].st.values[n] + rng.standard_normal(reps[0].st.values[n].shape) * 0.1).astype(np.float32)
+    for r in reps[1:]:
+        for n in r.st.values:
+            r.st.values[n] = reps[0].st.values[n].copy()
+    inputs = {"iters": np.array(iters)}
+    for n, v in reps[0].st.values.items():
+        inputs["w/" + n] = v
+    shape = (opts.batch_size, opts.output_height, opts.output_width, opts.c_dim)
+    for r in range(world):
+        for i in range(iters):
+            inputs["im/%d/%d" % (r, i)] = rng.uniform(-1, 1, shape).astype(np.float32)
+            inputs["z/%d/%d" % (r, i)] = rng.uniform(-1, 1, (opts.batch_size, opts.z_dim)).astype(np.float32)
+    np.savez(os.path.join(str(tmp_path), "inputs.npz"), **inputs)
+
+    got = launch("gpu", tmp_path, world)
+
+    # ranks were seeded differently; the constructor's broadcast made them equal
+    np.testing.assert_array_equal(got[0]["bcast/g_h0_lin"], got[1]["bcast/g_h0_lin"])
+
+    # two oracle replicas, per-replica batch-norm statistics, gradients averaged before each Adam step
+    def averaged(grads):
+        return {n: sum(g[n] for g in grads) / world for n in grads[0]}
+    want_losses = [[] for _ in range(world)]
+    d_sum = d_post = None
+    for i in range(iters):
+        grads, row = [], [[] for _ in range(world)]
+        for r, net in enumerate(reps):
+            tp = A.Tape(net.st)
+            lr_, lf_ = net.d_losses(tp, inputs["im/%d/%d" % (r, i)], inputs["z/%d/%d" % (r, i)])
+            tp.backward(A.add(tp, lr_, lf_))
+            grads.append(tp.grads(net.d_vars))
+            row[r] += [float(lr_.v), float(lf_.v)]
+        if i == 0:
+            d_sum = {n: sum(g[n] for g in grads) for n in grads[0]}
+        for net in reps:
+            net.d_adam.step(averaged(grads))
+        if i == 0:
+            d_post = {n: reps[0].st.values[n].copy() for n in reps[0].d_vars}
+        for _ in range(2):
+            grads = []
+            for r, net in enumerate(reps):
+                tp = A.Tape(net.st)
+                G = net.generator(tp, tp.const(inputs["z/%d/%d" % (r, i)]), None)
+                gl = A.sigmoid_ce_mean(tp, net.discriminator(tp, G, None), 1.0)
+                tp.backward(gl)
+                grads.append(tp.grads(net.g_vars))
+                row[r].append(float(gl.v))
+            for net in reps:
+                net.g_adam.step(averaged(grads))
+        for r in range(world):
+            want_losses[r].append(row[r])
+
+    for r in range(world):
+        # the gradient arena after the exchange holds the SUM over ranks (the mean is taken inside Adam)
+        for n in d_sum:
+            if is_noise_grad(n, d_sum):
+                continue
+            assert_close(got[r]["dgrad/" + n], d_sum[n], "rank %d summed grad %s" % (r, n), tol=3e-4)
+            # Adam's first step is lr * g / (|g| + eps): elements whose gradient is within rounding of
+            # zero move by a different fraction of lr, hence the looser bound on the weights
+            assert_close(got[r]["dpost/" + n], d_post[n], "rank %d post-Adam %s" % (r, n), tol=5e-4)
+        # stated tolerance: |loss - oracle| <= 2e-3 over the three iterations
+        np.testing.assert_allclose(got[r]["losses_eager"], np.array(want_losses[r]), rtol=0, atol=2e-3)
+        # the segmented HIP-graph runner is the same arithmetic as the eager iteration
+        np.testing.assert_array_equal(got[r]["losses_graph"], got[r]["losses_eager"])
+        for k in got[r].files:
+            if k.startswith("final/"):
+                np.testing.assert_array_equal(got[r]["final_graph/" + k[len("final/"):]], got[r][k])
+        assert list(got[r]["steps"]) == [iters, 2 * iters]
+    # replicas stay bit-identical in everything that is trained; moving averages are per replica
+    differs = 0
+    for k in got[0].files:
+        if not k.startswith("final/"):
+            continue
+        if 'moving_' in k:
+            differs += int(not np.array_equal(got[0][k], got[1][k]))
+        else:
+            np.testing.assert_array_equal(got[0][k], got[1][k])
+    assert differs > 0
