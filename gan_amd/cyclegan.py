@@ -6,6 +6,7 @@ part of the hot path; `train_iteration` takes the [N, s, s, 6] real_A|real_B ten
 from __future__ import division
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -190,6 +191,36 @@ class CycleGAN(object):
                 'g_loss_a2b': f('g_a2b_gan') + f('g_a2b_cyc_a') + f('g_a2b_cyc_b'),
                 'da_loss': f('da_loss_real') + f('da_loss_fake'),
                 'g_loss_b2a': f('g_b2a_gan') + f('g_b2a_cyc_a') + f('g_b2a_cyc_b')}
+
+    def train(self, dataA, dataB, max_iters=None, seed=0):
+        """cyclegan.py:137-190 for in-memory data: dataA / dataB are [N, s, s, c] float arrays in
+        [-1, 1] (what load_data yields, misc.py:288-289); both are shuffled every epoch and paired
+        by position, batches are the channel-wise concatenation real_A | real_B."""
+        opts = self.options
+        dev = self.store.device
+        rng = np.random.RandomState(seed)
+        counter = 1
+        start_time = time.time()
+        if self.load(opts.checkpoint_dir):
+            print(" [*] Load SUCCESS")
+        else:
+            print(" [!] Load failed...")
+        iters = 0
+        for epoch in range(opts.nEpochs):
+            ia, ib = rng.permutation(len(dataA)), rng.permutation(len(dataB))
+            batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // self.batch_size
+            for idx in range(0, batch_idxs):
+                sl = slice(idx * self.batch_size, (idx + 1) * self.batch_size)
+                batch = np.concatenate([np.asarray(dataA)[ia[sl]], np.asarray(dataB)[ib[sl]]], axis=3).astype(np.float32)
+                out = self.train_iteration(torch.from_numpy(batch).to(dev))
+                counter += 1
+                print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
+                if np.mod(counter, 1000) == 2:
+                    self.save(opts.checkpoint_dir, counter)
+                iters += 1
+                if max_iters is not None and iters >= max_iters:
+                    return out
+        return None
 
     def test(self, images, which_direction='AtoB'):
         """cyclegan.py:238-265 without the file I/O: translate a batch with one generator."""

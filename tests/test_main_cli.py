@@ -1,0 +1,65 @@
+"""The command line keeps the reference's flag surface (main.py:104-188) and dispatches the three
+GAN models (main.py:66-82)."""
+import numpy as np
+import pytest
+
+
+def parse(argv):
+    from gan_amd.main import build_parser
+    return build_parser().parse_args(argv)
+
+
+def test_defaults_match_the_reference_parser():
+    o = parse([])
+    want = dict(model='DCGAN', nEpochs=25, save_every_batch=50, print_every=1, batch_size=64, train_size=1e8,
+                load_size=286, fine_size=256, ngf=32, ndf=64, input_nc=3, output_nc=3, niter=200, lr=0.0002,
+                beta1=0.5, flip=True, which_direction='AtoB', phase='train', save_latest_freq=5000,
+                continue_train=False, serial_batches=False, serial_batch_iter=True, checkpoint_dir='./checkpoint',
+                sample_dir='./samples', test_dir='./test', L1_lambda=10.0, use_resnet=True, use_lsgan=True,
+                max_size=50, z_dim=100, t_dim=256, gf_dim=64, df_dim=64, gfc_dim=1024, dfc_dim=1024,
+                caption_vector_length=None, resume_model=None, input_height=108, input_width=None,
+                output_height=64, output_width=None, dataset='mnist', data_dir='data', log_dir='logs',
+                input_fname_pattern='*.jpg', crop=True, visualize=False, note='', textEncoder='skipthought')
+    for k, v in want.items():
+        assert getattr(o, k) == v, k
+
+
+def test_reference_script_command_lines_parse():
+    # scripts/DCGAN_mnist.sh, scripts/Text2Image_flowers.sh, scripts/CycleGAN.sh
+    o = parse("--dataset mnist --input_height 28 --output_height 28 --phase train".split())
+    assert (o.dataset, o.input_height, o.output_height) == ('mnist', 28, 28)
+    o = parse("--dataset flowers --input_height 64 --model Text2Image --nEpochs 200 --textEncoder DSSJE".split())
+    assert (o.model, o.textEncoder, o.nEpochs) == ('Text2Image', 'DSSJE', 200)
+    o = parse("--model CycleGAN --batch_size 1 --nEpochs 600 --dataset horse2zebra".split())
+    assert (o.model, o.batch_size, o.dataset) == ('CycleGAN', 1, 'horse2zebra')
+    assert parse(["--use_lsgan", "false"]).use_lsgan is False and parse(["--flip", "0"]).flip is False
+    with pytest.raises(SystemExit):
+        parse(["--use_lsgan", "maybe"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("argv", [
+    "--model DCGAN --dataset mnist --input_height 28 --output_height 28 --batch_size 8 --gf_dim 8 --df_dim 8 "
+    "--gfc_dim 32 --dfc_dim 32 --z_dim 16",
+    "--model DCGAN --dataset celebA --output_height 16 --batch_size 8 --gf_dim 8 --df_dim 8 --z_dim 16",
+    "--model Text2Image --dataset flowers --input_height 64 --textEncoder DSSJE --batch_size 4 --gf_dim 4 --df_dim 4 "
+    "--t_dim 8 --caption_vector_length 12 --z_dim 10",
+    "--model CycleGAN --dataset horse2zebra --batch_size 1 --fine_size 32 --gf_dim 4 --df_dim 4 --max_size 2",
+])
+def test_models_train_from_the_command_line_on_synthetic_data(argv, tmp_path):
+    from gan_amd.main import main
+    o = parse(argv.split() + ["--synthetic_iters", "3", "--checkpoint_dir", str(tmp_path / "ckpt"),
+                              "--sample_dir", str(tmp_path / "samples")])
+    out = main(o)
+    vals = [float(v) for v in out.values() if getattr(v, "numel", lambda: 0)() == 1]
+    assert len(vals) >= 4 and np.isfinite(vals).all()
+
+
+@pytest.mark.gpu
+def test_undefined_and_out_of_scope_models_raise(tmp_path):
+    from gan_amd.main import main
+    common = ["--checkpoint_dir", str(tmp_path / "c"), "--sample_dir", str(tmp_path / "s")]
+    with pytest.raises(Exception, match="undefined model"):
+        main(parse(["--model", "nope"] + common))
+    with pytest.raises(Exception, match="outside the accelerated"):
+        main(parse(["--model", "TextDecoder"] + common))
