@@ -526,6 +526,97 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// TPROP with a thin output (cb <= 4: the image-producing deconv of a generator, the input
+// gradient of a discriminator's first conv).  A 32-wide MFMA tile would be >= 87 % padding in N,
+// so this path runs on the vector ALUs instead: one thread owns one output pixel and its cb
+// accumulators, a block owns an 8 x 32 patch of one parity class of one image.  The patch's
+// input halo is staged through LDS in 16-channel chunks (coalesced 64-byte segments per pixel);
+// filter values are the same for every lane of the block (tap and channel are loop counters), so
+// they arrive through the scalar data path and feed the FMAs as scalar operands.
+// ------------------------------------------------------------------------------------------
+constexpr int kThinQH = 8, kThinQW = 32, kThinCC = 16, kThinPix = kThinCC + 4;  // padded pixel stride in LDS
+constexpr int kThinMaxTaps = 7;                                                  // per axis and class
+
+struct ThinArgs {
+    gan_conv_geom g;
+    const float* in;    // small image [n][hs][ws][cs]
+    const float* w;     // [kh][kw][cb][cs]
+    float* out;         // big image [n][hb][wb][cb]
+    const float* bias;  // [cb] or null
+    int ncls, tiles_h, tiles_w;
+    ClassInfo cls[kMaxClasses];
+};
+
+// MAXT bounds the taps per axis of any class and sizes the LDS halo (3: 5x5 stride 2 -> 27 KB, five
+// blocks per CU; 7: up to 7x7 stride 1 -> 42.5 KB).
+template <int CB, int MAXT>
+__global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
+    __shared__ __attribute__((aligned(16))) float tile[(kThinQH + MAXT - 1) * (kThinQW + MAXT - 1) * kThinPix];
+    const gan_conv_geom& g = p.g;
+    const int ci = blockIdx.y;
+    ClassInfo cl = p.cls[0];
+    if (ci == 1) cl = p.cls[1];
+    else if (ci == 2) cl = p.cls[2];
+    else if (ci == 3) cl = p.cls[3];
+    int b = blockIdx.x;
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h;
+    const int img = b / p.tiles_h;
+    const int qh_t = th * kThinQH, qw_t = tw * kThinQW;  // patch origin in the class grid
+    if (qh_t >= cl.hq || qw_t >= cl.wq) return;          // block-uniform: before any barrier
+    const int khc = cl.khc, kwc = cl.kwc;
+    const int RW = kThinQW + kwc - 1, RH = kThinQH + khc - 1;
+    // input rows / columns of the halo: i = (hq0 + q) - ta, ta in [0, khc)
+    const int i0 = cl.hq0 + qh_t - (khc - 1), j0 = cl.wq0 + qw_t - (kwc - 1);
+    const int lqh = threadIdx.x >> 5, lqw = threadIdx.x & 31;
+    const float* in_img = p.in + (long)img * g.hs * g.ws * g.cs;
+    float acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = 0.f;
+
+    for (int c0 = 0; c0 < g.cs; c0 += kThinCC) {
+        __syncthreads();
+        // thread -> (halo pixel, 4-channel group); 64 pixels further on every pass, kept as
+        // (row, column) without a division (RW >= 32, so at most two wraps per pass)
+        const int c4 = threadIdx.x & 3;
+        int r = 0, cc = threadIdx.x >> 2;
+        for (int pix = threadIdx.x >> 2; pix < RH * RW; pix += 64, cc += 64) {
+            while (cc >= RW) { cc -= RW; ++r; }
+            const int i = i0 + r, j = j0 + cc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i >= 0 && i < g.hs && j >= 0 && j < g.ws)
+                v = *reinterpret_cast<const float4*>(in_img + ((long)i * g.ws + j) * g.cs + c0 + c4 * 4);
+            *reinterpret_cast<float4*>(&tile[pix * kThinPix + c4 * 4]) = v;
+        }
+        __syncthreads();
+        for (int ta = 0; ta < khc; ++ta)
+            for (int tb = 0; tb < kwc; ++tb) {
+                const float* xp = &tile[((lqh + khc - 1 - ta) * RW + (lqw + kwc - 1 - tb)) * kThinPix];
+                float x[kThinCC];
+#pragma unroll
+                for (int k = 0; k < kThinCC; k += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xp + k);
+                    x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
+                }
+                // uniform address: tap (cl.ph + sh*ta, cl.pw + sw*tb), channels c0..c0+15
+                const float* wp = p.w + ((long)((cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb)) * g.cb) * g.cs + c0;
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+#pragma unroll
+                    for (int k = 0; k < kThinCC; ++k) acc[c] = fmaf(x[k], wp[(long)c * g.cs + k], acc[c]);
+                }
+            }
+    }
+    const int qh = qh_t + lqh, qw = qw_t + lqw;
+    if (qh < cl.hq && qw < cl.wq) {
+        const int h = (cl.hq0 + qh) * g.sh + cl.ph - g.pt, w = (cl.wq0 + qw) * g.sw + cl.pw - g.pl;
+        float* o = p.out + (((long)img * g.hb + h) * g.wb + w) * g.cb;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) o[c] = acc[c] + (p.bias ? p.bias[c] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct TileCfg {
@@ -640,6 +731,50 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     return pl;
 }
 
+// The vector-ALU path for thin TPROP outputs; a forced tile configuration (tests, tuning) keeps
+// the MFMA path.
+static bool thin_tprop_ok(const IgemmArgs& a) {
+    const gan_conv_geom& g = a.g;
+    if (g.cb > 4 || g.cs % kThinCC != 0 || a.accumulate) return false;
+    if (!aligned16(a.a) || getenv("GAN_HIP_FORCE_CFG") || getenv("GAN_HIP_NO_THIN")) return false;
+    for (int i = 0; i < a.ncls; ++i)
+        if (a.cls[i].khc > kThinMaxTaps || a.cls[i].kwc > kThinMaxTaps) return false;
+    return true;
+}
+
+static int run_thin_tprop(const IgemmArgs& a, hipStream_t s, const char* what) {
+    ThinArgs t;
+    t.g = a.g;
+    t.in = a.a; t.w = a.b; t.out = a.out; t.bias = a.bias;
+    t.ncls = a.ncls;
+    int hq = 0, wq = 0;
+    for (int i = 0; i < kMaxClasses; ++i) {
+        t.cls[i] = a.cls[i < a.ncls ? i : 0];
+        if (i < a.ncls && a.cls[i].hq > hq) hq = a.cls[i].hq;
+        if (i < a.ncls && a.cls[i].wq > wq) wq = a.cls[i].wq;
+    }
+    t.tiles_h = (hq + kThinQH - 1) / kThinQH;
+    t.tiles_w = (wq + kThinQW - 1) / kThinQW;
+    if (t.tiles_h < 1 || t.tiles_w < 1) return 0;
+    dim3 grid((unsigned)(a.g.n * t.tiles_h * t.tiles_w), (unsigned)a.ncls);
+    int maxt = 0;
+    for (int i = 0; i < a.ncls; ++i) {
+        if (a.cls[i].khc > maxt) maxt = a.cls[i].khc;
+        if (a.cls[i].kwc > maxt) maxt = a.cls[i].kwc;
+    }
+#define GAN_THIN_LAUNCH(CBV)                                                                            \
+    if (maxt <= 3) hipLaunchKernelGGL((tprop_thin_kernel<CBV, 3>), grid, dim3(256), 0, s, t);           \
+    else hipLaunchKernelGGL((tprop_thin_kernel<CBV, kThinMaxTaps>), grid, dim3(256), 0, s, t)
+    switch (a.g.cb) {
+        case 1: GAN_THIN_LAUNCH(1); break;
+        case 2: GAN_THIN_LAUNCH(2); break;
+        case 3: GAN_THIN_LAUNCH(3); break;
+        default: GAN_THIN_LAUNCH(4); break;
+    }
+#undef GAN_THIN_LAUNCH
+    return check_launch(what);
+}
+
 template <int MODE, int BM, int BN, int WM, int WN>
 static void launch_vec(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_t s) {
     if (pl.va == 4 && pl.vb == 4)
@@ -670,6 +805,7 @@ static size_t plan_ws_bytes(const Plan& pl) {
 int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what) {
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
+    if (mode == MODE_TPROP && thin_tprop_ok(a)) return run_thin_tprop(a, s, what);
     Plan pl = make_plan(mode, a);
     const size_t need = plan_ws_bytes(pl);
     GAN_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= need), "%s: workspace of %zu bytes needed, %zu given",

@@ -36,6 +36,12 @@ SMALL_CONVS = [
     (1, 22, 22, 3, 8, 7, 1, 'VALID'),
     (1, 16, 16, 12, 1, 5, 1, 'SAME'),      # cyclegan d_h3_pred: Cout = 1
     (2, 9, 13, 8, 12, 5, 2, 'SAME'),       # non-square, odd
+    # thin big side (cb <= 4) with cs a multiple of 16: the vector-ALU input-gradient path
+    (1, 22, 22, 3, 16, 7, 1, 'VALID'),
+    (2, 9, 13, 2, 32, 5, 2, 'SAME'),
+    (3, 28, 28, 1, 16, 5, 2, 'SAME'),
+    (2, 12, 12, 4, 16, 3, 2, 'SAME'),
+    (2, 70, 41, 3, 48, 5, 2, 'SAME'),      # several 8x32 patches per class, ragged edges
 ]
 
 DCGAN_CONVS = [

@@ -58,11 +58,15 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None, help="layer:pass, e.g. d_h1:fwd")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--cfg", default=None)
+    ap.add_argument("--splits", default=None)
     args = ap.parse_args()
     ws_bytes = 1 << 30
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
     wp, wn = ws.data_ptr(), ws_bytes
     for lname, (n, h, w_, cb, cs, k, s) in LAYERS:
+        n = args.batch
         g = ops._conv_geom(n, h, w_, cb, cs, k, k, s, s, 'SAME')
         big = torch.randn(n, h, w_, cb, device='cuda')
         small = torch.randn(n, g.hs, g.ws, cs, device='cuda')
@@ -76,6 +80,10 @@ def main():
                 continue
             os.environ.pop("GAN_HIP_FORCE_CFG", None)
             os.environ.pop("GAN_HIP_FORCE_SPLITS", None)
+            if args.cfg is not None:
+                os.environ["GAN_HIP_FORCE_CFG"] = args.cfg
+            if args.splits is not None:
+                os.environ["GAN_HIP_FORCE_SPLITS"] = args.splits
             us = time_pass(g, p, bufs, wp, wn, args.reps)
             print("%-5s %-6s heuristic        %8.1f us  %6.1f TFLOP/s" % (lname, p, us, flops / us / 1e6), flush=True)
             if not args.sweep:
