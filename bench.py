@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
     args = ap.parse_args()
@@ -144,8 +145,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from gan_amd import _lib
+    from gan_amd import _lib, autotune
     from gan_amd.dcgan import DCGAN
+    autotune.enable(not args.no_autotune)   # plans are tuned during model construction (eager), before capture
 
     model = DCGAN(None, dcgan64_opts(seed=0), world_size=world, load_data=False)
     # synthetic CelebA-shaped data, per-rank seed, resident in HBM before the timed region
@@ -207,7 +209,8 @@ def main():
             "config": {"workload": "DCGAN 64x64x3 CelebA-shaped synthetic images, batch 64 per GPU, fp32, "
                                    "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments + RCCL all-reduce")},
+                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments + RCCL all-reduce"),
+                       "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},
             "roofline": roof,
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             "losses_last_step": {k: round(v, 5) for k, v in losses.items()},

@@ -66,6 +66,10 @@ SIGNATURES = {
     "gan_l1_mean": (I, [P, P, L, F, I, P, P, P]),
     "gan_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P, P, P]),
     "gan_fill": (I, [P, L, F, P]),
+    "gan_conv_plan_set": (I, [I, GeomP, I, I]),
+    "gan_conv_plan_get": (I, [I, GeomP, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
+    "gan_conv_plan_clear": (None, []),
+    "gan_linear_as_conv_geom": (I, [I, I, I, GeomP]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
@@ -106,6 +110,7 @@ def stream():
 
 # ---------------------------------------------------------------------------- workspace
 _WS = {}
+_WS_RETIRED = []    # outgrown buffers stay allocated: captured graphs may still hold their address
 _WS_MIN = 64 << 20
 
 
@@ -117,6 +122,8 @@ def workspace(nbytes):
         if torch.cuda.is_current_stream_capturing():
             raise GanHipError("workspace of %d bytes needed during graph capture; run one eager step first" % nbytes)
         size = max(_WS_MIN, int(nbytes * 1.25))
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.empty(size, dtype=torch.uint8, device='cuda')
         _WS[dev] = buf
     return buf.data_ptr(), buf.numel()

@@ -10,6 +10,9 @@ namespace gan {
 enum { MODE_FPROP = 0, MODE_TPROP = 1, MODE_WGRAD = 2 };
 struct IgemmArgs;
 int conv_geom_check(const gan_conv_geom* g);
+int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits);
+void plan_get(int mode, const gan_conv_geom& g, int* cfg, int* splits, int* thin);
+void plan_clear();
 size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what);
@@ -147,5 +150,36 @@ extern "C" int gan_linear_wgrad(int rows, int in_dim, int out_dim, const float* 
                                 ws, ws_bytes, as_stream(stream), "gan_linear_wgrad"))
         return rc;
     if (dbias) return colsum(dy, dbias, rows, out_dim, accumulate, ws, ws_bytes, as_stream(stream), "gan_linear_wgrad");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- plan pinning
+static int plan_mode_check(const char* what, int mode) {
+    GAN_CHECK_ARG(mode >= MODE_FPROP && mode <= MODE_WGRAD, "%s: mode must be 0 (fprop), 1 (tprop) or 2 (wgrad)", what);
+    return 0;
+}
+
+extern "C" int gan_conv_plan_set(int mode, const gan_conv_geom* g, int cfg, int splits) {
+    if (int rc = plan_mode_check("gan_conv_plan_set", mode)) return rc;
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(cfg < 4, "gan_conv_plan_set: tile configuration must be 0..3 (or negative to unpin)");
+    GAN_CHECK_ARG(cfg < 0 || (splits >= 1 && splits <= 512), "gan_conv_plan_set: split factor must be in 1..512");
+    return plan_set(mode, *g, cfg, splits);
+}
+
+extern "C" int gan_conv_plan_get(int mode, const gan_conv_geom* g, int* cfg, int* splits, int* thin) {
+    if (int rc = plan_mode_check("gan_conv_plan_get", mode)) return rc;
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(cfg && splits && thin, "gan_conv_plan_get: NULL output");
+    plan_get(mode, *g, cfg, splits, thin);
+    return 0;
+}
+
+extern "C" void gan_conv_plan_clear(void) { plan_clear(); }
+
+extern "C" int gan_linear_as_conv_geom(int rows, int in_dim, int out_dim, gan_conv_geom* g) {
+    if (int rc = linear_check("gan_linear_as_conv_geom", rows, in_dim, out_dim)) return rc;
+    GAN_CHECK_ARG(g != nullptr, "gan_linear_as_conv_geom: NULL output");
+    *g = linear_geom(rows, in_dim, out_dim);
     return 0;
 }

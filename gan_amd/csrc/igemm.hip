@@ -25,6 +25,9 @@
 // the loop body is one basic block the compiler can interleave with the MFMAs.
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -680,6 +683,26 @@ static void build_classes(const gan_conv_geom& g, IgemmArgs& a) {
         }
 }
 
+// Pinned plans: (mode, geometry) -> (tile configuration, split-K factor), filled by the host-side
+// tuner.  Consulted by make_plan after the heuristic and before the environment overrides.
+struct PlanKey {
+    int v[14];
+    bool operator<(const PlanKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+
+static PlanKey plan_key(int mode, const gan_conv_geom& g) {
+    PlanKey k;
+    const int f[14] = {mode, g.n, g.hb, g.wb, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl};
+    memcpy(k.v, f, sizeof(f));
+    return k;
+}
+
+static std::map<PlanKey, std::pair<int, int>>& plan_table() {
+    static std::map<PlanKey, std::pair<int, int>> t;
+    return t;
+}
+static std::mutex g_plan_mu;
+
 static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 static Plan make_plan(int mode, const IgemmArgs& a) {
@@ -706,6 +729,15 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     if (N <= 32) pl.cfg = 3;
     else if (N <= 64) pl.cfg = (M >= 8192) ? 1 : 2;
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
+    int pinned_splits = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        auto it = plan_table().find(plan_key(mode, g));
+        if (it != plan_table().end()) {
+            pl.cfg = it->second.first;
+            pinned_splits = it->second.second;
+        }
+    }
     if (const char* e = getenv("GAN_HIP_FORCE_CFG")) pl.cfg = atoi(e) & 3;
     const int bm = kCfg[pl.cfg].bm, bn = kCfg[pl.cfg].bn;
     pl.mt = (M + bm - 1) / bm;
@@ -724,6 +756,7 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
         if (splits > 512) splits = 512;
         if (splits < 1) splits = 1;
     }
+    if (pinned_splits > 0) splits = pinned_splits;
     if (const char* e = getenv("GAN_HIP_FORCE_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : 1;
     pl.kt_per_split = nkt > 0 ? (nkt + splits - 1) / splits : 1;
     pl.splits = nkt > 0 ? (nkt + pl.kt_per_split - 1) / pl.kt_per_split : 1;
@@ -874,6 +907,30 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
         r.M = 0; r.N = g.cb; r.K = 0;
     }
     return r;
+}
+
+int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits) {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    if (cfg < 0) plan_table().erase(plan_key(mode, g));
+    else plan_table()[plan_key(mode, g)] = std::make_pair(cfg & 3, splits);
+    return 0;
+}
+
+void plan_clear() {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    plan_table().clear();
+}
+
+// The plan a call with 16-byte aligned operands would run with right now.
+void plan_get(int mode, const gan_conv_geom& g, int* cfg, int* splits, int* thin) {
+    static const float dummy[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    IgemmArgs a = make_args(mode, g, dummy, dummy, nullptr, nullptr, 0);
+    if (mode == MODE_TPROP) build_classes(a.g, a);
+    else a.ncls = 1;
+    const Plan pl = make_plan(mode, a);
+    *cfg = pl.cfg;
+    *splits = pl.splits;
+    *thin = (mode == MODE_TPROP && thin_tprop_ok(a)) ? 1 : 0;
 }
 
 int conv_geom_check(const gan_conv_geom* g) {

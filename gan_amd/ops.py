@@ -23,6 +23,7 @@ import math
 import torch
 
 from . import _lib
+from . import autotune
 from . import variables as V
 from ._lib import ACT_CODES, check, lib, ptr, stream
 
@@ -70,6 +71,7 @@ def _conv_geom(n, h, w, c_big, c_small, k_h, k_w, d_h, d_w, padding, small_hw=No
 
 
 _ws_cache = {}
+autotune.on_change(_ws_cache.clear)     # pinned plans change the split-K workspace sizes
 
 
 def _conv_ws(g):
@@ -204,6 +206,8 @@ def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding=
         w = st.get_variable('w', [k_h, k_w, cin, output_dim], V.truncated_normal_initializer(stddev))
         biases = st.get_variable('biases', [output_dim], V.constant_initializer(0.0))
     g = _conv_geom(n, h, w_, cin, output_dim, k_h, k_w, d_h, d_w, padding)
+    if autotune.enabled():
+        autotune.tune_geometry(g)
     return _Conv2dFn.apply(input_, _grad_token(input_.device), w, biases, g)
 
 
@@ -219,6 +223,8 @@ def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name
         w = st.get_variable('w', [k_h, k_w, oc, cin], V.random_normal_initializer(stddev))
         biases = st.get_variable('biases', [oc], V.constant_initializer(0.0))
     g = _conv_geom(n, oh, ow, oc, cin, k_h, k_w, d_h, d_w, 'SAME', small_hw=(hs, ws))
+    if autotune.enabled():
+        autotune.tune_geometry(g)
     deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device), w, biases, g)
     if with_w:
         return deconv, w, biases
@@ -233,6 +239,8 @@ def linear(input_, output_size, scope_name=None, stddev=0.02, bias_start=0.0, wi
     with st.variable_scope(scope_name or "Linear", reuse=reuse):
         matrix = st.get_variable("Matrix", [input_.shape[1], output_size], V.random_normal_initializer(stddev))
         bias = st.get_variable("bias", [output_size], V.constant_initializer(bias_start))
+    if autotune.enabled():
+        autotune.tune_linear(int(input_.shape[0]), int(input_.shape[1]), int(output_size))
     y = _LinearFn.apply(input_, _grad_token(input_.device), matrix, bias)
     if with_w:
         return y, matrix, bias

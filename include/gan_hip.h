@@ -165,6 +165,23 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
                      float beta1, float beta2, float eps, float grad_scale, int* step_dev,
                      float* lr_scratch, gan_stream_t stream);
 
+/* ---- plan pinning (no counterpart in the reference: TensorFlow picks its conv algorithms
+ * internally; this is the hook a host-side autotuner uses) ------------------------------------
+ * Every conv / deconv / linear pass is one of three contractions over the geometry:
+ *   mode 0: conv2d_fwd, deconv2d_dgrad, linear_fwd
+ *   mode 1: conv2d_dgrad, deconv2d_fwd, linear_dgrad
+ *   mode 2: conv2d_wgrad, deconv2d_wgrad, linear_wgrad
+ * gan_conv_plan_set pins the tile configuration (0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32) and
+ * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
+ * gan_conv_plan_get reports the plan in effect (`thin` = 1 when mode 1 takes the vector-ALU path
+ * for outputs of <= 4 channels, which has no plan).  Changing a plan changes the workspace size
+ * gan_conv_workspace_bytes reports.  gan_linear_as_conv_geom yields the geometry under which
+ * the linear entry points look their plan up. */
+int gan_conv_plan_set(int mode, const gan_conv_geom* g, int cfg, int splits);
+int gan_conv_plan_get(int mode, const gan_conv_geom* g, int* cfg, int* splits, int* thin);
+void gan_conv_plan_clear(void);
+int gan_linear_as_conv_geom(int rows, int in_dim, int out_dim, gan_conv_geom* g);
+
 /* ---- utilities ------------------------------------------------------------------------- */
 int gan_fill(float* x, long n, float value, gan_stream_t stream);
 

@@ -40,3 +40,39 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_plan_pinning_is_host_side_bookkeeping():
+    """gan_conv_plan_set / _get / _clear need no GPU: a pinned plan is what the planner reports, the
+    workspace query follows it, and removing the pin restores the heuristic."""
+    import ctypes
+    from gan_amd import _lib as L
+    g = L.conv_geom(64, 16, 16, 128, 8, 8, 256, 5, 5, 2, 2, 1, 1)
+    gp = ctypes.byref(g)
+    c, s, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+
+    def get(mode):
+        L.check(L.lib.gan_conv_plan_get(mode, gp, ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+        return c.value, s.value, thin.value
+    L.lib.gan_conv_plan_clear()
+    heur = get(0)
+    ws0 = L.lib.gan_conv_workspace_bytes(gp)
+    L.check(L.lib.gan_conv_plan_set(0, gp, 2, 1))
+    L.check(L.lib.gan_conv_plan_set(1, gp, 2, 1))
+    L.check(L.lib.gan_conv_plan_set(2, gp, 2, 1))
+    assert get(0) == (2, 1, 0) and get(1)[:2] == (2, 1)
+    assert L.lib.gan_conv_workspace_bytes(gp) < ws0 or ws0 == 0     # splits == 1 needs no slabs
+    L.check(L.lib.gan_conv_plan_set(0, gp, 0, 7))
+    assert get(0)[0] == 0 and 1 < get(0)[1] <= 7       # the planner may round the split count down
+    L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
+    assert get(0) == heur
+    assert L.lib.gan_conv_plan_set(3, gp, 0, 1) != 0 and b"mode" in L.lib.gan_last_error()
+    assert L.lib.gan_conv_plan_set(0, gp, 4, 1) != 0
+    # thin outputs of the transposed contraction have no plan
+    g3 = L.conv_geom(64, 64, 64, 3, 32, 32, 64, 5, 5, 2, 2, 1, 1)
+    L.check(L.lib.gan_conv_plan_get(1, ctypes.byref(g3), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+    assert thin.value == 1
+    lg = L.ConvGeom()
+    L.check(L.lib.gan_linear_as_conv_geom(64, 100, 8192, ctypes.byref(lg)))
+    assert (lg.n, lg.cb, lg.cs, lg.kh, lg.hb) == (64, 100, 8192, 1, 1)
+    L.lib.gan_conv_plan_clear()

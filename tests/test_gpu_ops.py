@@ -439,3 +439,22 @@ def test_argument_errors_are_reported(L):
     assert b"stride" in L.lib.gan_last_error()
     with pytest.raises(L.GanHipError):
         L.ptr(torch.zeros(4))          # host tensor: no CPU path
+
+
+def test_autotuned_plans_keep_parity(L):
+    """Tuning pins some plan for each mode of the geometry; results stay within the parity bar and
+    the pins disappear on reset."""
+    from gan_amd import autotune
+    case = (4, 16, 16, 32, 64, 5, 2, 'SAME')
+    from gpu_util import geom_for
+    g = geom_for(*case)
+    try:
+        res = autotune.tune_geometry(g, reps=2)
+        assert set(res) == {0, 1, 2} and all(us > 0 for _, _, us, _ in res.values())
+        assert autotune.tune_geometry(g) is res          # cached
+        _conv_case(L, case)
+        lin = autotune.tune_linear(8, 40, 24, reps=2)
+        assert set(lin) == {0, 1, 2}
+    finally:
+        autotune.reset()
+    assert autotune.report() == {}
