@@ -210,6 +210,8 @@ def main():
                                    "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments + RCCL all-reduce"),
+                       "schedule": ("the first G update reuses the D update's generator pass (same z, same weights; "
+                                    "results identical to re-running it)" if world == 1 else "run-by-run"),
                        "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},
             "roofline": roof,
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -52,6 +52,7 @@ SIGNATURES = {
     "gan_linear_wgrad": (I, [I, I, I, P, P, P, P, I, P, Z, P]),
     "gan_bn_workspace_bytes": (Z, [I, I, I]),
     "gan_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, I, F, P, Z, P]),
+    "gan_bn_moving_update": (I, [P, P, P, P, I, I, F, F, I, P]),
     "gan_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, F, I, F, P]),
     "gan_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, Z, P]),
     "gan_act_fwd": (I, [P, P, L, I, F, F, F, P]),

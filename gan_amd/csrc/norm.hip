@@ -437,6 +437,29 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     return check_launch("gan_bn_fwd_train");
 }
 
+// moving <- momentum*moving + (1-momentum)*batch from the statistics a training forward saved
+__global__ void bn_moving_update_kernel(float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                        const float* __restrict__ save_mean, const float* __restrict__ save_rstd, int c,
+                                        float n, float eps, float momentum, int unbiased) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float rs = save_rstd[ch];
+    float var = fmaxf(1.0f / (rs * rs) - eps, 0.f);
+    if (unbiased) var *= n / fmaxf(n - 1.f, 1.f);
+    moving_mean[ch] = moving_mean[ch] * momentum + save_mean[ch] * (1.f - momentum);
+    moving_var[ch] = moving_var[ch] * momentum + var * (1.f - momentum);
+}
+
+extern "C" int gan_bn_moving_update(float* moving_mean, float* moving_var, const float* save_mean,
+                                    const float* save_rstd, int rows, int c, float eps, float momentum,
+                                    int unbiased_moving_var, gan_stream_t stream) {
+    GAN_CHECK_ARG(rows > 0 && c > 0, "gan_bn_moving_update: rows and c must be positive");
+    GAN_CHECK_ARG(moving_mean && moving_var && save_mean && save_rstd, "gan_bn_moving_update: NULL tensor");
+    hipLaunchKernelGGL(bn_moving_update_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), moving_mean,
+                       moving_var, save_mean, save_rstd, c, (float)rows, eps, momentum, unbiased_moving_var);
+    return check_launch("gan_bn_moving_update");
+}
+
 extern "C" int gan_bn_fwd_eval(const float* x, const float* gamma, const float* beta, const float* moving_mean,
                                const float* moving_var, float* y, int rows, int c, float eps, int act,
                                float act_param, gan_stream_t stream) {

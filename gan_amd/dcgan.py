@@ -193,14 +193,25 @@ class DCGAN(object):
             return self.generator(z, y, train=False)
 
     # ------------------------------------------------------------------------------------ updates
-    def d_grads(self, images, z, y=None):
+    def d_grads(self, images, z, y=None, keep_g=False):
         """Forward + backward of d_loss w.r.t. d_vars (the gradient half of minimize, dcgan.py:154-155):
         leaves the local gradients in the d group's arena.  Returns (d_loss_real, d_loss_fake) as
-        1-element device tensors (d_loss is their sum, dcgan.py:139)."""
+        1-element device tensors (d_loss is their sum, dcgan.py:139).
+
+        keep_g=True records the generator pass (activations and batch-norm statistics) so that the
+        next g_grads(reuse_g=True) on the same z / y, with the generator's weights untouched in
+        between, does not run it again."""
         with V.use_store(self.store):
             self.d_optim.begin()
-            with torch.no_grad():
-                G = self.generator(z, y)                       # gradients stop at d_vars: no G tape
+            self._g_pass = None
+            if keep_g:
+                with ops.moving_update_log() as log:
+                    G_taped = self.generator(z, y)
+                self._g_pass = (G_taped, log, z, y)
+                G = G_taped.detach()                           # gradients stop at d_vars
+            else:
+                with torch.no_grad():
+                    G = self.generator(z, y)                   # gradients stop at d_vars: no G tape
             _, D_logits = self.discriminator(images, y, reuse=False)
             _, D_logits_ = self.discriminator(G, y, reuse=True)
             d_loss_real = ops.sigmoid_cross_entropy_mean(D_logits, 1.0)      # dcgan.py:129-132
@@ -209,27 +220,38 @@ class DCGAN(object):
             self.d_optim.finish_grads()
         return d_loss_real.detach(), d_loss_fake.detach()
 
-    def g_grads(self, z, y=None):
-        """Forward + backward of g_loss w.r.t. g_vars (through D, whose weights get no gradient)."""
+    def g_grads(self, z, y=None, reuse_g=False):
+        """Forward + backward of g_loss w.r.t. g_vars (through D, whose weights get no gradient).
+
+        The reference evaluates G(z) once in the d_optim run and again in the first g_optim run
+        (dcgan.py:228-247) with the same z and the same generator weights: the second evaluation
+        repeats the first bit for bit.  reuse_g=True takes the pass d_grads(keep_g=True) recorded
+        instead of recomputing it, and applies the batch-norm moving-average updates that second
+        evaluation would have made."""
         with V.use_store(self.store):
             self.g_optim.begin()
-            G = self.generator(z, y)
+            kept, self._g_pass = getattr(self, '_g_pass', None), None
+            if reuse_g and kept is not None and kept[2] is z and kept[3] is y:
+                G, log = kept[0], kept[1]
+                log.replay()
+            else:
+                G = self.generator(z, y)
             _, D_logits_ = self.discriminator(G, y, reuse=True)
             g_loss = ops.sigmoid_cross_entropy_mean(D_logits_, 1.0)          # dcgan.py:133-134
             ops.backward(g_loss)
             self.g_optim.finish_grads()
         return g_loss.detach()
 
-    def d_update(self, images, z, y=None):
+    def d_update(self, images, z, y=None, keep_g=False):
         """sess.run([d_optim, ...]) of dcgan.py:228-233 / 263-264."""
-        losses = self.d_grads(images, z, y)
+        losses = self.d_grads(images, z, y, keep_g=keep_g)
         self.d_optim.all_reduce(self.world_size, self.process_group)
         self.d_optim.adam(self.world_size)
         return losses
 
-    def g_update(self, z, y=None):
+    def g_update(self, z, y=None, reuse_g=False):
         """sess.run([g_optim, ...]) of dcgan.py:237-247 / 268-275."""
-        g_loss = self.g_grads(z, y)
+        g_loss = self.g_grads(z, y, reuse_g=reuse_g)
         self.g_optim.all_reduce(self.world_size, self.process_group)
         self.g_optim.adam(self.world_size)
         return g_loss
@@ -243,10 +265,18 @@ class DCGAN(object):
             errG = ops.sigmoid_cross_entropy_mean(self.discriminator(self.generator(z, y), y, reuse=True)[1], 1.0)
         return errD_fake, errD_real, errG
 
-    def train_iteration(self, images, z, y=None, log_evals=False):
-        """One iteration of the loop body dcgan.py:226-279."""
-        d_real, d_fake = self.d_update(images, z, y)
-        g1 = self.g_update(z, y)
+    def train_iteration(self, images, z, y=None, log_evals=False, share_g_pass=None):
+        """One iteration of the loop body dcgan.py:226-279.
+
+        share_g_pass (default: on for a single process) lets the first generator update reuse the
+        generator pass of the discriminator update instead of repeating it; the results are those
+        of the run-by-run schedule (share_g_pass=False).  The data-parallel paths keep the
+        run-by-run schedule so that the eager and the segmented-graph iteration stay the same
+        sequence of kernels."""
+        if share_g_pass is None:
+            share_g_pass = self.world_size == 1 and self.process_group is None
+        d_real, d_fake = self.d_update(images, z, y, keep_g=share_g_pass)
+        g1 = self.g_update(z, y, reuse_g=share_g_pass)
         # Run g_optim twice to make sure that d_loss does not go to zero (different from paper)
         g2 = self.g_update(z, y)
         out = {'d_loss_real': d_real, 'd_loss_fake': d_fake, 'g_loss_1': g1, 'g_loss_2': g2}

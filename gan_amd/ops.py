@@ -250,6 +250,30 @@ def linear(input_, output_size, scope_name=None, stddev=0.02, bias_start=0.0, wi
 # --------------------------------------------------------------------------------------------
 # batch norm / instance norm (fused with the activation that follows)
 # --------------------------------------------------------------------------------------------
+class moving_update_log(object):
+    """Collects, for every training-mode batch norm run inside the block, what is needed to apply
+    its moving-average update once more (`replay`).  A model uses it to reuse one forward pass for
+    two of the reference's session runs that evaluate the same sub-graph on the same inputs and
+    weights: the activations are shared, the moving averages still move twice."""
+
+    current = None
+
+    def __init__(self):
+        self.entries = []
+
+    def __enter__(self):
+        self.previous, moving_update_log.current = moving_update_log.current, self
+        return self
+
+    def __exit__(self, *exc):
+        moving_update_log.current = self.previous
+
+    def replay(self):
+        for mm, mv, mean, rstd, rows, c, eps, momentum, unbiased in self.entries:
+            check(lib.gan_bn_moving_update(ptr(mm.data), ptr(mv.data), ptr(mean), ptr(rstd), rows, c, eps, momentum,
+                                           int(unbiased), stream()))
+
+
 class _NormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, token, gamma, beta, mm, mv, groups, eps, momentum, unbiased, act, act_param):
@@ -265,6 +289,8 @@ class _NormFn(torch.autograd.Function):
                                    None if mm is None else ptr(mm.data), None if mv is None else ptr(mv.data),
                                    ptr(res), ptr(y), ptr(save_mean), ptr(save_rstd), groups, rows, c,
                                    eps, momentum, int(unbiased), act, act_param, wp, wn, stream()))
+        if moving_update_log.current is not None and mm is not None:
+            moving_update_log.current.entries.append((mm, mv, save_mean, save_rstd, rows, c, eps, momentum, unbiased))
         ctx.save_for_backward(x, save_mean, save_rstd)
         ctx.gamma, ctx.beta = gamma, beta
         ctx.cfg = (groups, rows, c, act, act_param)

@@ -106,6 +106,13 @@ int gan_bn_fwd_train(const float* x, const float* gamma, const float* beta, floa
                      float* save_rstd, int groups, int rows, int c, float eps, float momentum,
                      int unbiased_moving_var, int act, float act_param, void* ws, size_t ws_bytes,
                      gan_stream_t stream);
+/* The moving-average side effect of one more training forward on the same batch, from the
+ * statistics gan_bn_fwd_train saved (groups == 1): what a second sess.run of an unchanged
+ * sub-graph does to moving_mean / moving_variance (dcgan.py:228-247 runs the generator once per
+ * run with identical weights and z), without recomputing the activations. */
+int gan_bn_moving_update(float* moving_mean, float* moving_var, const float* save_mean,
+                         const float* save_rstd, int rows, int c, float eps, float momentum,
+                         int unbiased_moving_var, gan_stream_t stream);
 /* Inference forward (train=False, dcgan.py:427-436): uses the moving statistics. */
 int gan_bn_fwd_eval(const float* x, const float* gamma, const float* beta, const float* moving_mean,
                     const float* moving_var, float* y, int rows, int c, float eps, int act,

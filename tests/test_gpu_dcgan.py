@@ -203,3 +203,26 @@ def test_checkpoint_round_trip(tmp_path):
     got = other.train_iteration(im, z)
     for k in expect:
         assert float(expect[k]) == float(got[k])      # Adam slots and step counts came back too
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_shared_generator_pass_equals_run_by_run_schedule(cond):
+    """Reusing the D update's generator pass in the first G update changes nothing that is trained
+    (bitwise) and moves the batch-norm moving averages like the second evaluation would have."""
+    opts = make_opts(y_dim=4, c_dim=1, output_height=12, output_width=12, input_height=12) if cond else make_opts()
+    _, a, rng = build_pair(opts, seed=13)
+    _, b, _ = build_pair(opts, seed=13)
+    for _ in range(3):
+        im, z, y = to_dev(*batch(opts, rng, lo=0.0 if cond else -1.0))
+        oa = a.train_iteration(im, z, y, share_g_pass=True)
+        ob = b.train_iteration(im, z, y, share_g_pass=False)
+        torch.cuda.synchronize()
+        for k in oa:
+            assert float(oa[k]) == float(ob[k]), k
+    for name, v in a.store.vars.items():
+        w = b.store.vars[name]
+        if 'moving_' in name:
+            torch.testing.assert_close(v.data, w.data, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(v.data, w.data), name
+    assert a.g_optim.steps_taken == b.g_optim.steps_taken == 6
