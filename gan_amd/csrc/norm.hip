@@ -418,7 +418,6 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     if (int rc = bn_args_check("gan_bn_fwd_train", groups, rows, c, act)) return rc;
     GAN_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd, "gan_bn_fwd_train: NULL tensor");
     GAN_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "gan_bn_fwd_train: moving_mean and moving_var must be given together");
-    GAN_CHECK_ARG(moving_mean == nullptr || groups == 1, "gan_bn_fwd_train: moving statistics require groups == 1");
     const size_t need = bn_ws_bytes(groups, rows, c);
     GAN_CHECK_ARG(ws && ws_bytes >= need, "gan_bn_fwd_train: workspace of %zu bytes needed, %zu given", need, ws_bytes);
     const BnShape s = bn_shape(groups, rows, c);
@@ -429,8 +428,20 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     else
         hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(s.rblocks, groups, (c + kChanTile - 1) / kChanTile), dim3(256), 0,
                            st, x, partial, s);
-    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((groups * c + 3) / 4), dim3(256), 0, st, partial, save_mean,
-                       save_rstd, moving_mean, moving_var, s, eps, momentum, unbiased_moving_var);
+    if (moving_mean != nullptr && groups > 1) {
+        // several passes through one layer stacked along the batch axis: each group is one pass and
+        // moves the averages in turn, so the groups are finalised one launch after the other
+        BnShape one = s;
+        one.groups = 1;
+        for (int grp = 0; grp < groups; ++grp)
+            hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((c + 3) / 4), dim3(256), 0, st,
+                               partial + (size_t)grp * s.rblocks * c, save_mean + (size_t)grp * c,
+                               save_rstd + (size_t)grp * c, moving_mean, moving_var, one, eps, momentum,
+                               unbiased_moving_var);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((groups * c + 3) / 4), dim3(256), 0, st, partial, save_mean,
+                           save_rstd, moving_mean, moving_var, s, eps, momentum, unbiased_moving_var);
+    }
     const long total = (long)groups * rows * c;
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for((c & 3) ? total : total / 4)), dim3(256), 0, st, x, gamma,
                        beta, save_mean, save_rstd, residual, y, groups, rows, c, eps, act, act_param);

@@ -60,6 +60,7 @@ class DCGAN(object):
 
         self.world_size = world_size
         self.process_group = process_group
+        self.stack_d_passes = True      # D update: D(real) and D(fake) as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
 
         # batch normalization : deals with poor initialization helps gradient flow (dcgan.py:56-68)
@@ -125,29 +126,35 @@ class DCGAN(object):
         self.counter = 1
 
     # ------------------------------------------------------------------------------------ networks
-    def discriminator(self, image, y=None, reuse=False):
-        """dcgan.py:322-351.  Returns (sigmoid(h), h) like the reference."""
+    def discriminator(self, image, y=None, reuse=False, passes=1, with_prob=True):
+        """dcgan.py:322-351.  Returns (sigmoid(h), h) like the reference.
+
+        passes=k: `image` (and `y`) hold k batches stacked along axis 0 and the call stands for k
+        applications of the network (shared weights, batch-norm statistics per batch).
+        with_prob=False skips the sigmoid of the first return value (None then), which the training
+        losses never read (they are built on the logits, dcgan.py:129-134)."""
+        bs = self.batch_size * passes
         with ops.variable_scope("discriminator") as scope:
             if reuse:
                 scope.reuse_variables()
             if not self.y_dim:
                 h0 = lrelu(conv2d(image, self.df_dim, name='d_h0_conv'))
-                h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu')
-                h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu')
-                h3 = self.d_bn3(conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu')
-                h4 = linear(h3.reshape(self.batch_size, -1), 1, 'd_h3_lin')
-                return _sigmoid_value(h4), h4
-            yb = y.reshape(self.batch_size, 1, 1, self.y_dim)
+                h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)
+                h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)
+                h3 = self.d_bn3(conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu', passes=passes)
+                h4 = linear(h3.reshape(bs, -1), 1, 'd_h3_lin')
+                return (_sigmoid_value(h4) if with_prob else None), h4
+            yb = y.reshape(bs, 1, 1, self.y_dim)
             x = conv_cond_concat(image, yb)
             h0 = lrelu(conv2d(x, self.c_dim + self.y_dim, name='d_h0_conv'))
             h0 = conv_cond_concat(h0, yb)
-            h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv'), act='lrelu')
-            h1 = h1.reshape(self.batch_size, -1)
+            h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv'), act='lrelu', passes=passes)
+            h1 = h1.reshape(bs, -1)
             h1 = concat([h1, y], 1)
-            h2 = self.d_bn2(linear(h1, self.dfc_dim, 'd_h2_lin'), act='lrelu')
+            h2 = self.d_bn2(linear(h1, self.dfc_dim, 'd_h2_lin'), act='lrelu', passes=passes)
             h2 = concat([h2, y], 1)
             h3 = linear(h2, 1, 'd_h3_lin')
-            return _sigmoid_value(h3), h3
+            return (_sigmoid_value(h3) if with_prob else None), h3
 
     def generator(self, z, y=None, train=True):
         """dcgan.py:353-410 (and, with train=False, the sampler of :412-462)."""
@@ -212,10 +219,18 @@ class DCGAN(object):
             else:
                 with torch.no_grad():
                     G = self.generator(z, y)                   # gradients stop at d_vars: no G tape
-            _, D_logits = self.discriminator(images, y, reuse=False)
-            _, D_logits_ = self.discriminator(G, y, reuse=True)
-            d_loss_real = ops.sigmoid_cross_entropy_mean(D_logits, 1.0)      # dcgan.py:129-132
-            d_loss_fake = ops.sigmoid_cross_entropy_mean(D_logits_, 0.0)
+            if self.stack_d_passes:
+                # D(real) and D(fake) share weights and differ only in their batch-norm statistics:
+                # both passes run as one batch of 2B with per-half statistics (dcgan.py:113-114)
+                both = ops.stack_batches(images, G)
+                y2 = None if y is None else ops.stack_batches(y, y)
+                _, logits = self.discriminator(both, y2, reuse=True, passes=2, with_prob=False)
+                d_loss_real, d_loss_fake = ops.stacked_sigmoid_cross_entropy_means(logits, 1.0, 0.0)
+            else:
+                _, D_logits = self.discriminator(images, y, reuse=False)
+                _, D_logits_ = self.discriminator(G, y, reuse=True)
+                d_loss_real = ops.sigmoid_cross_entropy_mean(D_logits, 1.0)      # dcgan.py:129-132
+                d_loss_fake = ops.sigmoid_cross_entropy_mean(D_logits_, 0.0)
             ops.backward([d_loss_real, d_loss_fake])
             self.d_optim.finish_grads()
         return d_loss_real.detach(), d_loss_fake.detach()
@@ -236,7 +251,7 @@ class DCGAN(object):
                 log.replay()
             else:
                 G = self.generator(z, y)
-            _, D_logits_ = self.discriminator(G, y, reuse=True)
+            _, D_logits_ = self.discriminator(G, y, reuse=True, with_prob=False)
             g_loss = ops.sigmoid_cross_entropy_mean(D_logits_, 1.0)          # dcgan.py:133-134
             ops.backward(g_loss)
             self.g_optim.finish_grads()

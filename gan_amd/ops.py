@@ -289,7 +289,7 @@ class _NormFn(torch.autograd.Function):
                                    None if mm is None else ptr(mm.data), None if mv is None else ptr(mv.data),
                                    ptr(res), ptr(y), ptr(save_mean), ptr(save_rstd), groups, rows, c,
                                    eps, momentum, int(unbiased), act, act_param, wp, wn, stream()))
-        if moving_update_log.current is not None and mm is not None:
+        if moving_update_log.current is not None and mm is not None and groups == 1:
             moving_update_log.current.entries.append((mm, mv, save_mean, save_rstd, rows, c, eps, momentum, unbiased))
         ctx.save_for_backward(x, save_mean, save_rstd)
         ctx.gamma, ctx.beta = gamma, beta
@@ -326,7 +326,9 @@ class batch_norm(object):
     Extensions (keyword-only, default to the reference behaviour): `act` / `act_param` fuse the
     activation that follows; `residual` is added after it (the ResNet block's `y + x`).
     `unbiased_moving_var` picks the Bessel-corrected batch variance for the moving average, which is
-    what TensorFlow's fused kernel feeds it (the unfused one feeds the biased value: default)."""
+    what TensorFlow's fused kernel feeds it (the unfused one feeds the biased value: default).
+    `passes` = k treats x as k equal batches stacked along axis 0, each normalised with its own
+    statistics and each moving the averages in turn: k applications of the layer in one call."""
 
     unbiased_moving_var = False
 
@@ -335,7 +337,7 @@ class batch_norm(object):
         self.momentum = momentum
         self.name = name
 
-    def __call__(self, x, train=True, act=None, act_param=0.2, residual=None):
+    def __call__(self, x, train=True, act=None, act_param=0.2, residual=None, passes=1):
         st = V.default_store()
         c = x.shape[-1]
         with st.variable_scope(self.name):
@@ -345,7 +347,9 @@ class batch_norm(object):
             mv = st.get_variable('moving_variance', [c], V.constant_initializer(1.0), trainable=False)
         code = ACT_CODES[act]
         if train:
-            return _NormFn.apply(x, residual, _grad_token(x.device), gamma, beta, mm, mv, 1, float(self.epsilon),
+            if x.shape[0] % passes:
+                raise ValueError("batch_norm: batch of %d does not split into %d passes" % (x.shape[0], passes))
+            return _NormFn.apply(x, residual, _grad_token(x.device), gamma, beta, mm, mv, int(passes), float(self.epsilon),
                                  float(self.momentum), self.unbiased_moving_var, code, float(act_param))
         if residual is not None:
             raise ValueError("batch_norm(train=False) does not take a residual")
@@ -540,6 +544,46 @@ def sigmoid_cross_entropy_mean(logits, label, weight=1.0):
     """tf.reduce_mean(tf.nn.sigmoid_cross_entropy_with_logits(logits, labels=const)) * weight
     (dcgan.py:123-134, text2image.py:86-90, cyclegan_module.py:155-156)."""
     return _LossFn.apply('bce', logits, None, float(label), float(weight))
+
+
+class _StackedBceFn(torch.autograd.Function):
+    """Two sigmoid cross-entropy means over the two halves of a stacked batch of logits."""
+
+    @staticmethod
+    def forward(ctx, logits, label_a, label_b, weight):
+        x = _dense(logits)
+        n = x.numel() // 2
+        la = torch.empty(1, dtype=torch.float32, device=x.device)
+        lb = torch.empty(1, dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gp = ptr(grad)
+        check(lib.gan_sigmoid_bce_mean(ptr(x), n, label_a, weight, 0, ptr(la), gp, stream()))
+        check(lib.gan_sigmoid_bce_mean(ptr(x) + 4 * n, n, label_b, weight, 0, ptr(lb),
+                                       None if gp is None else gp + 4 * n, stream()))
+        ctx.grad = grad
+        return la, lb
+
+    @staticmethod
+    def backward(ctx, _one_a, _one_b):
+        return ctx.grad, None, None, None
+
+
+def stacked_sigmoid_cross_entropy_means(logits, label_first, label_second, weight=1.0):
+    """(mean CE of the first half against label_first, mean CE of the second half against
+    label_second) of logits that hold two stacked batches; both are roots for backward()."""
+    if logits.shape[0] % 2:
+        raise ValueError("stacked logits need an even batch, got %d" % logits.shape[0])
+    return _StackedBceFn.apply(logits, float(label_first), float(label_second), float(weight))
+
+
+def stack_batches(a, b):
+    """[a; b] along axis 0 in one new buffer (two device copies)."""
+    if a.shape != b.shape:
+        raise ValueError("stack_batches: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    out[:a.shape[0]].copy_(a.detach())
+    out[a.shape[0]:].copy_(b.detach())
+    return out
 
 
 def mse_const_mean(x, target, weight=1.0):

@@ -97,7 +97,8 @@ int gan_linear_wgrad(int rows, int in_dim, int out_dim, const float* x, const fl
  * the reference's CycleGAN gets it implicitly from batch_norm at batch 1).
  * Training forward: y = act(gamma*(x-mean)*rsqrt(var+eps)+beta) + residual (residual may be NULL),
  * biased variance; saves mean and rstd ([groups][c] each) for the backward; when moving_mean /
- * moving_var are non-NULL (groups must be 1) updates them in place:
+ * moving_var are non-NULL updates them in place, once per group in group order (groups > 1 with
+ * moving statistics = several passes through the same layer stacked along the batch axis):
  * moving = momentum*moving + (1-momentum)*batch, with the batch variance multiplied by
  * rows/(rows-1) when unbiased_moving_var != 0. */
 size_t gan_bn_workspace_bytes(int groups, int rows, int c);

@@ -274,3 +274,43 @@ def test_instance_norm_equals_per_sample_batch_norm():
     assert_close(y.detach().cpu().numpy(), np.concatenate(ys), "instance norm fwd")
     assert_close(xt.grad.cpu().numpy(), np.concatenate(dxs), "instance norm dx", tol=3e-4)
     assert_close(st.vars['in0/gamma'].grad.cpu().numpy(), dg, "instance norm dgamma", tol=3e-4)
+
+
+def test_batch_norm_stacked_passes_equal_separate_calls():
+    """batch_norm(passes=2) on [a; b] == the layer applied to a and then to b: outputs, input
+    gradients, accumulated gamma/beta gradients and the twice-moved moving averages."""
+    from gan_amd import ops, variables as V
+    from gpu_util import assert_close, host
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((4, 5, 5, 8)).astype(np.float32) * 2 + 1
+    b = rng.standard_normal((4, 5, 5, 8)).astype(np.float32) - 0.5
+    dy = rng.standard_normal((8, 5, 5, 8)).astype(np.float32)
+    res = []
+    for stacked in (False, True):
+        st = V.VariableStore(seed=0)
+        with V.use_store(st):
+            bn = ops.batch_norm(name='bn')
+            ta, tb = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+            bn(ta, act='lrelu')                                   # creates the variables
+            for n in ('bn/moving_mean',):
+                st.vars[n].data.zero_()
+            st.vars['bn/moving_variance'].data.fill_(1.0)
+            st.vars['bn/gamma'].data.copy_(dev(np.linspace(0.5, 1.5, 8)))
+            grp = st.pack('g', st.trainable_variables())
+            grp.begin_update()
+            if stacked:
+                both = ops.stack_batches(ta, tb).requires_grad_(True)
+                y = bn(both, act='lrelu', passes=2)
+                y.backward(dev(dy))
+                dx = host(both.grad)
+            else:
+                ya, yb = bn(ta, act='lrelu'), bn(tb, act='lrelu')
+                y = torch.cat([ya, yb])
+                torch.autograd.backward([ya, yb], [dev(dy[:4]), dev(dy[4:])])
+                dx = np.concatenate([host(ta.grad), host(tb.grad)])
+            grp.end_update()
+        torch.cuda.synchronize()
+        res.append((host(y), dx, host(st.vars['bn/gamma'].grad), host(st.vars['bn/beta'].grad),
+                    host(st.vars['bn/moving_mean'].data), host(st.vars['bn/moving_variance'].data)))
+    for got, want, what in zip(res[1], res[0], ("y", "dx", "dgamma", "dbeta", "moving_mean", "moving_variance")):
+        assert_close(got, want, "stacked batch_norm " + what, tol=1e-6)
