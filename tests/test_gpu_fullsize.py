@@ -1,0 +1,168 @@
+"""The BASELINE configurations at their full sizes, where the numpy oracle is too slow to run whole:
+size-independent properties of the contraction kernels on every CycleGAN-256 / Text2Image layer shape
+(the trilinear identity <conv(x,w),dy> = <x,dgrad(dy,w)> = <w,wgrad(x,dy)> plus oracle spot checks of
+sampled output pixels), the full-size y-conditioned MNIST DCGAN against the oracle, and full-size
+Text2Image / CycleGAN iterations (graph replay == eager, finite losses and gradients)."""
+import argparse
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(4242)
+
+# n, h, w, cb, cs, k, s, padding  (conv2d view: big [n,h,w,cb] -> small [n,.,.,cs])
+FULL_SHAPES = [
+    (1, 262, 262, 3, 64, 7, 1, 'VALID'),      # cyclegan g_e1_c on the reflect-padded image
+    (1, 256, 256, 64, 128, 3, 2, 'SAME'),     # g_e2_c; transposed: g_d2_dc
+    (1, 128, 128, 128, 256, 3, 2, 'SAME'),    # g_e3_c; transposed: g_d1_dc
+    (1, 66, 66, 256, 256, 3, 1, 'VALID'),     # the 18 residual-block convolutions
+    (1, 262, 262, 64, 3, 7, 1, 'VALID'),      # g_pred_c
+    (1, 256, 256, 3, 64, 5, 2, 'SAME'),       # cyclegan d_h0_conv
+    (1, 128, 128, 64, 128, 5, 2, 'SAME'),
+    (1, 64, 64, 128, 256, 5, 2, 'SAME'),
+    (1, 32, 32, 256, 512, 5, 1, 'SAME'),      # d_h3_conv, stride 1
+    (1, 32, 32, 512, 1, 5, 1, 'SAME'),        # d_h3_pred
+    (64, 4, 4, 768, 512, 1, 1, 'SAME'),       # text2image d_h3_conv_new (1x1 on the text-concatenated map)
+    (64, 28, 28, 11, 11, 5, 2, 'SAME'),       # MNIST d_h0_conv
+    (64, 14, 14, 138, 128, 5, 2, 'SAME'),     # MNIST g_h2 (transposed)
+]
+
+
+@pytest.mark.parametrize("case", FULL_SHAPES)
+def test_trilinear_identity_and_spot_checks_at_full_size(case):
+    from gan_amd import _lib as L
+    from gpu_util import dev, geom_for, host
+    n, h, w, cb, cs, k, s, padding = case
+    g = geom_for(*case)
+    x = RNG.standard_normal((n, h, w, cb)).astype(np.float32)
+    wt = (RNG.standard_normal((k, k, cb, cs)) * 0.05).astype(np.float32)
+    dy = RNG.standard_normal((n, g.hs, g.ws, cs)).astype(np.float32)
+    xd, wd, dyd = dev(x), dev(wt), dev(dy)
+    y = torch.empty((n, g.hs, g.ws, cs), device='cuda')
+    dx = torch.empty_like(xd)
+    dw = torch.empty_like(wd)
+    db = torch.empty(cs, device='cuda')
+    gp = ctypes.byref(g)
+    wp, wn = L.workspace(int(L.lib.gan_conv_workspace_bytes(gp)))
+    st = L.stream()
+    L.check(L.lib.gan_conv2d_fwd(gp, L.ptr(xd), L.ptr(wd), None, L.ptr(y), wp, wn, st))
+    L.check(L.lib.gan_conv2d_dgrad(gp, L.ptr(dyd), L.ptr(wd), L.ptr(dx), wp, wn, st))
+    L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(db), 0, wp, wn, st))
+    torch.cuda.synchronize()
+    yh = host(y).astype(np.float64)
+    s1 = float((yh * dy).sum())
+    s2 = float((host(dx).astype(np.float64) * x).sum())
+    s3 = float((host(dw).astype(np.float64) * wt).sum())
+    scale = float(np.abs(yh * dy).sum())            # the size of what cancels in the three sums
+    assert abs(s1 - s2) <= 1e-6 * scale and abs(s1 - s3) <= 1e-6 * scale, (s1, s2, s3, scale)
+    np.testing.assert_allclose(host(db), dy.reshape(-1, cs).sum(0, dtype=np.float64), rtol=0,
+                               atol=1e-4 * float(np.abs(dy).sum(axis=(0, 1, 2)).max()))
+    # oracle spot checks: sampled output pixels recomputed in float64 from the definition
+    # y[n,i,j,:] = sum_{a,b,c} x[n, i*s+a-pt, j*s+b-pl, c] * w[a,b,c,:]   (ops.py:68, TF SAME/VALID)
+    ymax = float(np.abs(yh).max())
+    for _ in range(24):
+        b_, i, j = RNG.integers(0, n), RNG.integers(0, g.hs), RNG.integers(0, g.ws)
+        if _ < 8:                                    # force border pixels in
+            i, j = [0, g.hs - 1][_ % 2], [0, g.ws - 1][(_ // 2) % 2]
+        acc = np.zeros(cs)
+        for a in range(k):
+            for b in range(k):
+                r, c = i * s + a - g.pt, j * s + b - g.pl
+                if 0 <= r < h and 0 <= c < w:
+                    acc += x[b_, r, c].astype(np.float64) @ wt[a, b].astype(np.float64)
+        assert np.abs(yh[b_, i, j] - acc).max() <= 1e-4 * ymax, (case, b_, i, j)
+
+
+def test_mnist_conditional_dcgan_full_size_against_oracle():
+    """BASELINE config 0 (scripts/DCGAN_mnist.sh): batch 64, 28x28x1, y_dim 10, z 100, default widths."""
+    from oracle import autodiff as A
+    from oracle import nets
+    from gan_amd.dcgan import DCGAN
+    from gpu_util import dev
+    opts = argparse.Namespace(model='DCGAN', dataset='mnist', batch_size=64, input_height=28, input_width=28,
+                              output_height=28, output_width=28, y_dim=10, z_dim=100, gf_dim=64, df_dim=64,
+                              gfc_dim=1024, dfc_dim=1024, c_dim=1, lr=0.0002, beta1=0.5, crop=True, nEpochs=1,
+                              train_size=1e8, print_every=1, checkpoint_dir='./checkpoint', seed=0)
+    st = A.Store(seed=3)
+    ref = nets.DCGAN(st, batch_size=64, output_height=28, output_width=28, c_dim=1, y_dim=10, z_dim=100,
+                     gf_dim=64, df_dim=64, gfc_dim=1024, dfc_dim=1024, lr=0.0002, beta1=0.5)
+    ref.build(np.zeros((64, 28, 28, 1), np.float32), np.zeros((64, 100), np.float32), np.zeros((64, 10), np.float32))
+    gpu = DCGAN(None, opts, load_data=False)
+    assert list(gpu.store.vars) == list(st.values)
+    gpu.store.load_state_dict(st.values)
+    rng = np.random.default_rng(3)
+    for it in range(2):
+        im = rng.uniform(0, 1, (64, 28, 28, 1)).astype(np.float32)
+        z = rng.uniform(-1, 1, (64, 100)).astype(np.float32)
+        y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 64)]
+        want = ref.train_iteration(im, z, y)
+        out = gpu.train_iteration(dev(im), dev(z), dev(y))
+        got = {'d_loss': float(out['d_loss_real']) + float(out['d_loss_fake']),
+               'g_loss_1': float(out['g_loss_1']), 'g_loss_2': float(out['g_loss_2'])}
+        for k_ in got:      # stated tolerance: 2e-3 relative on the losses of the first two iterations
+            assert abs(got[k_] - want[k_]) <= 2e-3 * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
+
+
+def _finite_grads(optims):
+    for o in optims:
+        assert bool(torch.isfinite(o.group.grads).all())
+        assert float(o.group.grads.abs().max()) > 0
+
+
+def test_text2image_full_size_graph_replay_equals_eager():
+    from gan_amd.graph import CapturedIteration, model_state_restore, model_state_snapshot
+    from gan_amd.main import build_parser
+    from gan_amd.text2image import Text2Image
+    from gpu_util import dev
+    o = build_parser().parse_args("--dataset flowers --input_height 64 --model Text2Image --textEncoder DSSJE".split())
+    eager, graphed = Text2Image(None, o), Text2Image(None, o)
+    graphed.store.load_state_dict(eager.store.state_dict())
+    rng = np.random.default_rng(1)
+    batches = [[dev(rng.uniform(0, 1, (64, 64, 64, 3))), dev(rng.uniform(0, 1, (64, 64, 64, 3))),
+                dev(rng.standard_normal((64, 1024))), dev(rng.uniform(-1, 1, (64, 100)))] for _ in range(2)]
+    optims = [graphed.d_optim, graphed.g_optim]
+    fn = lambda a, b, c, d: {k: v for k, v in graphed.train_iteration(a, b, c, d).items() if k != 'generator'}
+    step = CapturedIteration(fn, batches[0], snapshot=lambda: model_state_snapshot(graphed.store, optims),
+                             restore=lambda s: model_state_restore(graphed.store, optims, s))
+    for b in batches:
+        e = eager.train_iteration(*b)
+        g = step(*b)
+        torch.cuda.synchronize()
+        for k in g:
+            assert np.isfinite(float(e[k])) and float(e[k]) == float(g[k]), k
+    _finite_grads([eager.d_optim, eager.g_optim])
+    for name, v in eager.store.vars.items():
+        assert torch.equal(v.data, graphed.store.vars[name].data), name
+    gen = e['generator']
+    assert gen.shape == (64, 64, 64, 3) and 0.0 <= float(gen.min()) and float(gen.max()) <= 1.0
+
+
+def test_cyclegan_full_size_iteration():
+    """256x256, gf_dim = df_dim = 64, batch 1: two iterations run, losses and gradients are finite,
+    the untrained LSGAN discriminator losses sit near their known starting values, the image pool
+    hands back what it stored, and repeating the run from the same state gives the same numbers."""
+    from gan_amd.cyclegan import CycleGAN
+    from gan_amd.main import build_parser
+    from gpu_util import dev
+    o = build_parser().parse_args("--model CycleGAN --batch_size 1 --dataset horse2zebra --max_size 2".split())
+    rng = np.random.default_rng(2)
+    data = [dev(rng.uniform(-1, 1, (1, 256, 256, 6))) for _ in range(2)]
+    runs = []
+    for _ in range(2):
+        m = CycleGAN(None, o)
+        outs = [CycleGAN.totals(m.train_iteration(d)) for d in data]
+        torch.cuda.synchronize()
+        runs.append(outs)
+        _finite_grads(list(m.optims.values()))
+        assert m.pool.num_img == 2 and all(opt.steps_taken == 2 for opt in m.optims.values())
+        out = m.test(data[0][..., :3].contiguous(), 'AtoB')
+        assert out.shape == (1, 256, 256, 3) and float(out.abs().max()) <= 1.0
+    for a, b in zip(*runs):
+        for k in a:
+            assert np.isfinite(a[k]) and a[k] == b[k], k
+    # cycle terms: L1_lambda * mean|x - G(G(x))| of U(-1,1) images against a tanh output is O(lambda * 0.5)
+    assert 1.0 < runs[0][0]['g_loss_a2b'] < 30.0 and 0.0 < runs[0][0]['db_loss'] < 5.0
