@@ -127,9 +127,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="one GPU only: run the data-parallel path (segmented graphs + RCCL all-reduce) on a one-rank group")
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
     args = ap.parse_args()
 
+    # Libraries underneath (RCCL's version banner) write to stdout; the contract is ONE JSON line
+    # there, so everything before the final print goes to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -140,16 +147,23 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    pg = None
+    if world > 1 or args.rehearse_dp:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            pg = dist.group.WORLD
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from gan_amd import _lib, autotune
     from gan_amd.dcgan import DCGAN
     autotune.enable(not args.no_autotune)   # plans are tuned during model construction (eager), before capture
 
-    model = DCGAN(None, dcgan64_opts(seed=0), world_size=world, load_data=False)
+    model = DCGAN(None, dcgan64_opts(seed=0), world_size=world, process_group=pg, load_data=False)
     # synthetic CelebA-shaped data, per-rank seed, resident in HBM before the timed region
     rng = np.random.default_rng(1000 + rank)
     pool = [(torch.from_numpy(rng.uniform(-1, 1, (BATCH, 64, 64, 3)).astype(np.float32)).cuda(),
@@ -209,9 +223,10 @@ def main():
             "config": {"workload": "DCGAN 64x64x3 CelebA-shaped synthetic images, batch 64 per GPU, fp32, "
                                    "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph segments + RCCL all-reduce"),
-                       "schedule": ("the first G update reuses the D update's generator pass (same z, same weights; "
-                                    "results identical to re-running it)" if world == 1 else "run-by-run"),
+                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 and pg is None
+                                                               else "hipGraph segments + RCCL all-reduce"),
+                       "schedule": "the first G update reuses the D update's generator pass (same z, same weights; "
+                                   "results identical to re-running it)",
                        "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},
             "roofline": roof,
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -219,7 +234,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_iters)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -283,13 +283,11 @@ class DCGAN(object):
     def train_iteration(self, images, z, y=None, log_evals=False, share_g_pass=None):
         """One iteration of the loop body dcgan.py:226-279.
 
-        share_g_pass (default: on for a single process) lets the first generator update reuse the
-        generator pass of the discriminator update instead of repeating it; the results are those
-        of the run-by-run schedule (share_g_pass=False).  The data-parallel paths keep the
-        run-by-run schedule so that the eager and the segmented-graph iteration stay the same
-        sequence of kernels."""
+        share_g_pass (default on) lets the first generator update reuse the generator pass of the
+        discriminator update instead of repeating it; the results are those of the run-by-run
+        schedule (share_g_pass=False)."""
         if share_g_pass is None:
-            share_g_pass = self.world_size == 1 and self.process_group is None
+            share_g_pass = True
         d_real, d_fake = self.d_update(images, z, y, keep_g=share_g_pass)
         g1 = self.g_update(z, y, reuse_g=share_g_pass)
         # Run g_optim twice to make sure that d_loss does not go to zero (different from paper)
@@ -304,10 +302,11 @@ class DCGAN(object):
         """The loop body dcgan.py:226-275 as replayable HIP graphs over static input buffers.
 
         One GPU: the whole iteration is one graph.  Data parallel: the iteration is cut at its three
-        gradient exchanges into four graphs (D backward | D Adam + G pass 1 | G Adam + G pass 2 |
-        G Adam) and the all-reduces of the flat gradient arenas are issued between them on the same
-        stream.  Returns run(images, z, y=None) -> the dict train_iteration returns."""
-        from .graph import CapturedIteration, model_state_restore, model_state_snapshot
+        gradient exchanges into four graphs sharing one memory pool (D pass + backward | D Adam +
+        G update 1 | G Adam + G update 2 | G Adam) and the all-reduces of the flat gradient arenas
+        are issued between them on the same stream.  Returns run(images, z, y=None) -> the dict
+        train_iteration returns."""
+        from .graph import CapturedIteration, SegmentedIteration, model_state_restore, model_state_snapshot
         optims = [self.d_optim, self.g_optim]
         snap = lambda: model_state_snapshot(self.store, optims)
         rest = lambda s: model_state_restore(self.store, optims, s)
@@ -320,7 +319,7 @@ class DCGAN(object):
                     dst.copy_(src, non_blocking=True)
 
         if segmented is None:
-            segmented = ws > 1
+            segmented = ws > 1 or pg is not None
         if not segmented:
             whole = CapturedIteration(lambda a, b, c: self.train_iteration(a, b, c), static, snap, rest, share_inputs=True)
 
@@ -329,31 +328,11 @@ class DCGAN(object):
                 return whole(*static)
             return run
 
-        def seg2(a, b, c):
-            self.d_optim.adam(ws)
-            return self.g_grads(b, c)
-
-        def seg3(a, b, c):
-            self.g_optim.adam(ws)
-            return self.g_grads(b, c)
-
-        def seg4(a, b, c):
-            self.g_optim.adam(ws)
-        s1 = CapturedIteration(lambda a, b, c: self.d_grads(a, b, c), static, snap, rest, share_inputs=True)
-        s2 = CapturedIteration(seg2, static, snap, rest, share_inputs=True)
-        s3 = CapturedIteration(seg3, static, snap, rest, share_inputs=True)
-        s4 = CapturedIteration(seg4, static, snap, rest, share_inputs=True)
+        chain = SegmentedIteration(lambda a, b, c: self.train_iteration(a, b, c), static, snap, rest)
 
         def run(im, zz, yy=None):
             refresh(im, zz, yy)
-            d_real, d_fake = s1(*static)
-            self.d_optim.all_reduce(ws, pg)
-            g1 = s2(*static)
-            self.g_optim.all_reduce(ws, pg)
-            g2 = s3(*static)
-            self.g_optim.all_reduce(ws, pg)
-            s4(*static)
-            return {'d_loss_real': d_real, 'd_loss_fake': d_fake, 'g_loss_1': g1, 'g_loss_2': g2}
+            return chain()
         return run
 
     # ------------------------------------------------------------------------------------ train loop

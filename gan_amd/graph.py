@@ -48,6 +48,86 @@ class CapturedIteration(object):
         return self.outputs
 
 
+class SegmentedIteration(object):
+    """Capture `fn(*inputs)` as a CHAIN of HIP graphs, cut at every point where `fn` has to do
+    something a graph cannot hold -- here the gradient all-reduces of data-parallel training.
+
+    While the capture pass runs, code inside `fn` calls `SegmentedIteration.cut(callback)` (the
+    optimiser's all_reduce does): the graph under construction is closed, `callback` is remembered
+    as the eager action between two graphs, and a new graph is opened in the same memory pool, so
+    tensors and the autograd tape made in one segment stay valid in the next.  A replay runs
+    graph, callback, graph, callback, ... on the current stream.  Outside a capture pass `cut`
+    simply runs the callback, which is what the eager warm-up runs do."""
+
+    active = None
+
+    def __init__(self, fn, example_inputs, snapshot=None, restore=None, warmup=2):
+        self.static_inputs = list(example_inputs)          # the caller owns and refreshes them
+        saved = snapshot() if snapshot is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn(*self.static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if restore is not None:
+            restore(saved)
+        saved = snapshot() if snapshot is not None else None
+        self.chain = []             # [(graph, callback or None)]
+        self._stream = torch.cuda.Stream()
+        self._pool = torch.cuda.graph_pool_handle()
+        self._capturing = False
+        SegmentedIteration.active = self
+        try:
+            self._open()
+            self.outputs = fn(*self.static_inputs)
+            self._close(None)
+        finally:
+            SegmentedIteration.active = None
+            if self._capturing:             # fn raised: leave the stream out of capture mode
+                try:
+                    self._graph.capture_end()
+                finally:
+                    self._ctx.__exit__(None, None, None)
+                    self._capturing = False
+        torch.cuda.synchronize()
+        if restore is not None:
+            restore(saved)
+
+    def _open(self):
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        self._graph = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.stream(self._stream)
+        self._ctx.__enter__()
+        self._graph.capture_begin(pool=self._pool)
+        self._capturing = True
+
+    def _close(self, callback):
+        self._graph.capture_end()
+        self._capturing = False
+        self._ctx.__exit__(None, None, None)
+        self.chain.append((self._graph, callback))
+
+    @classmethod
+    def cut(cls, callback):
+        self = cls.active
+        if self is None:
+            callback()
+            return
+        self._close(callback)
+        self._open()
+
+    def __call__(self):
+        for graph, callback in self.chain:
+            graph.replay()
+            if callback is not None:
+                callback()
+        return self.outputs
+
+
 def model_state_snapshot(store, optims):
     """Clone everything a training iteration mutates."""
     snap = {'vars': {n: v.data.clone() for n, v in store.vars.items() if v.group is None},

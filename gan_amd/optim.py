@@ -39,19 +39,24 @@ class AdamOptimizer(object):
         self.group.end_update()
 
     def all_reduce(self, world_size=1, process_group=None):
-        """Sum the group's flat gradient arena over the ranks (one collective per update)."""
+        """Sum the group's flat gradient arena over the ranks (one collective per update).  Inside a
+        segmented graph capture this is a cut: the collective runs eagerly between two graphs."""
         if world_size > 1 or process_group is not None:
-            import torch.distributed as dist
-            grads = self.group.grads
-            if grads.is_cuda and dist.get_backend(process_group) == "gloo":
-                # gloo (CPU rigs and rehearsals with several ranks on one GPU) moves host memory:
-                # stage the arena through the host explicitly instead of relying on gloo's own
-                # device-tensor path, which was seen to stall behind a replayed HIP graph
-                host = grads.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
-                grads.copy_(host)
-            else:
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=process_group)
+            from .graph import SegmentedIteration
+            SegmentedIteration.cut(lambda: self._all_reduce_now(process_group))
+
+    def _all_reduce_now(self, process_group):
+        import torch.distributed as dist
+        grads = self.group.grads
+        if grads.is_cuda and dist.get_backend(process_group) == "gloo":
+            # gloo (CPU rigs and rehearsals with several ranks on one GPU) moves host memory:
+            # stage the arena through the host explicitly instead of relying on gloo's own
+            # device-tensor path, which was seen to stall behind a replayed HIP graph
+            host = grads.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+            grads.copy_(host)
+        else:
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=process_group)
 
     def adam(self, world_size=1):
         """The fused TF-Adam step; the 1/world_size gradient average is applied inside the kernel."""
