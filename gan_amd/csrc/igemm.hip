@@ -73,6 +73,7 @@ struct IgemmArgs {
     int splits, kt_per_split;
     long slab_elems;
     int accumulate;
+    int vec_epilogue;  // rows of the output are 16-byte aligned and N % 4 == 0: float4 stores
     int ncls;
     FastDiv d_cb, d_cs, d_kw, d_hsws, d_ws;
     ClassInfo cls[kMaxClasses];
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
     // ---------------------------------------------------------------- epilogue
     // Row -> output offset table (element offset of channel 0, or -1), built once per block.
-    int* rowoff = reinterpret_cast<int*>(smem);
+    __shared__ int rowoff[BM];
     if (tid < BM) {
         const int m = m0 + tid;
         int off = -1;
@@ -430,6 +431,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     float* dst = p.out + (p.splits > 1 ? (long)split * p.slab_elems : 0L);
     const bool direct = p.splits == 1;
     const bool accum = direct && p.accumulate;
+
+    if (p.vec_epilogue) {
+        // The accumulators sit row-per-register; dword-per-lane stores of them are issue bound.
+        // Transpose through LDS instead (the operand buffers are free now) and let every lane store
+        // 16 bytes of one output row: R rows of the tile per pass.
+        constexpr int R = ((2 * STAGE) / BN / 32) * 32 < BM ? ((2 * STAGE) / BN / 32) * 32 : BM;
+        static_assert(R >= 32, "LDS staging must hold a 32-row group of the tile");
+        constexpr int F4_ROW = BN / 4;
+        const bool has_bias = direct && p.bias != nullptr;
+#pragma unroll
+        for (int r0 = 0; r0 < BM; r0 += R) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int gbase = wm * (BM / WM) + i * 32;     // first tile row of this 32-row group
+                if (gbase >= r0 && gbase < r0 + R) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = gbase - r0 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            smem[row * BN + wn * (BN / WN) + j * 32 + (lane & 31)] = acc[i][j][r];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f = tid; f < R * F4_ROW; f += 256) {
+                const int row = f / F4_ROW, c4 = f - row * F4_ROW;
+                const int off = (r0 + row < BM) ? rowoff[r0 + row] : -1;
+                const int col = n0 + c4 * 4;
+                if (off >= 0 && col < N) {
+                    float4 v = *reinterpret_cast<const float4*>(&smem[row * BN + c4 * 4]);
+                    if (has_bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    float4* o = reinterpret_cast<float4*>(dst + off + col);
+                    if (accum) {
+                        const float4 old = *o;
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    }
+                    *o = v;
+                }
+            }
+            if (r0 + R < BM) __syncthreads();
+        }
+        return;
+    }
+
     int ncol[TN];
     float bias_v[TN];
 #pragma unroll
@@ -854,6 +904,11 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         a.bias = nullptr;
         a.accumulate = 0;
     }
+    {
+        const int n_out = (mode == MODE_TPROP) ? a.g.cb : a.N;
+        a.vec_epilogue = ((n_out & 3) == 0 && (pl.out_elems & 3) == 0 && aligned16(a.out) && aligned16(final_out) &&
+                          (bias == nullptr || aligned16(bias)) && !getenv("GAN_HIP_SCALAR_EPILOGUE")) ? 1 : 0;
+    }
     dim3 grid(pl.mt, pl.nt, pl.splits * a.ncls);
     switch (mode) {
         case MODE_FPROP: launch_cfg<MODE_FPROP>(a, pl, grid, s); break;
@@ -892,7 +947,7 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.g = g;
     r.a = a; r.b = b; r.out = out; r.bias = bias;
     r.accumulate = accumulate;
-    r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1;
+    r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1; r.vec_epilogue = 0;
     r.d_cb = make_fastdiv((unsigned)g.cb);
     r.d_cs = make_fastdiv((unsigned)g.cs);
     r.d_kw = make_fastdiv((unsigned)g.kw);
