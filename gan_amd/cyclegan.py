@@ -117,13 +117,38 @@ class CycleGAN(object):
         self.g_a2b_optim, self.g_b2a_optim = self.optims['g_a2b'], self.optims['g_b2a']
 
     # ------------------------------------------------------------------------------------ runs
-    def forward_fakes(self, real_data):
-        """sess.run([self.fake_A, self.fake_B]) (cyclegan.py:160-161)."""
+    def forward_fakes(self, real_data, keep=False):
+        """sess.run([self.fake_A, self.fake_B]) (cyclegan.py:160-161).
+
+        keep=True records both generator passes (activations + batch-norm statistics) so that the
+        generator updates of the same iteration can take them instead of evaluating
+        G_A2B(real_A) / G_B2A(real_B) again while that generator's weights are still unchanged."""
         real_A, real_B = self.split(real_data)
-        with V.use_store(self.store), torch.no_grad():
-            fake_B = self.generator(real_A, self.options, True, name="generatorA2B")
-            fake_A = self.generator(real_B, self.options, True, name="generatorB2A")
-        return fake_A, fake_B
+        self._kept = {}
+        with V.use_store(self.store):
+            if keep:
+                with ops.taping():
+                    with ops.moving_update_log() as log_b:
+                        fake_B = self.generator(real_A, self.options, True, name="generatorA2B")
+                    with ops.moving_update_log() as log_a:
+                        fake_A = self.generator(real_B, self.options, True, name="generatorB2A")
+                self._kept = {'a2b': (fake_B, log_b, real_data), 'b2a': (fake_A, log_a, real_data)}
+            else:
+                with torch.no_grad():
+                    fake_B = self.generator(real_A, self.options, True, name="generatorA2B")
+                    fake_A = self.generator(real_B, self.options, True, name="generatorB2A")
+        return fake_A.detach(), fake_B.detach()
+
+    def _first_pass(self, direction, real_data, source, want_tape):
+        """G_<direction>(source image) for a generator update: the pass forward_fakes kept, while that
+        generator has not been updated since (its moving averages still move as if it were
+        evaluated again), or a fresh evaluation."""
+        kept = self._kept.get(direction) if getattr(self, '_kept', None) else None
+        name = "generatorA2B" if direction == 'a2b' else "generatorB2A"
+        if kept is not None and kept[2] is real_data:
+            kept[1].replay()
+            return kept[0] if want_tape else kept[0].detach()
+        return self.generator(source, self.options, True, name=name)
 
     def _finish(self, optim):
         optim.finish_grads()
@@ -150,9 +175,11 @@ class CycleGAN(object):
         optim = self.g_a2b_optim if which == 'a2b' else self.g_b2a_optim
         with V.use_store(self.store):
             optim.begin()
-            fake_B = self.generator(real_A, self.options, True, name="generatorA2B")
+            # the generator being updated needs its pass on tape; the other one only supplies a
+            # constant input (tf.gradients prunes it the same way)
+            fake_B = self._first_pass('a2b', real_data, real_A, want_tape=(which == 'a2b'))
             fake_A_ = self.generator(fake_B, self.options, True, name="generatorB2A")
-            fake_A = self.generator(real_B, self.options, True, name="generatorB2A")
+            fake_A = self._first_pass('b2a', real_data, real_B, want_tape=(which == 'b2a'))
             fake_B_ = self.generator(fake_A, self.options, True, name="generatorA2B")
             if which == 'a2b':
                 gan = self.criterionGAN(self.discriminator(fake_B, self.options, reuse=True, name="discriminatorB"), 1.0)
@@ -162,13 +189,15 @@ class CycleGAN(object):
             cyc_b = abs_criterion(real_B, fake_B_, self.L1_lambda)
             ops.backward([gan, cyc_a, cyc_b])
             self._finish(optim)
+            if getattr(self, '_kept', None):
+                self._kept.pop(which, None)         # this generator's weights have moved
         return gan.detach(), cyc_a.detach(), cyc_b.detach()
 
     def train_iteration(self, real_data):
         """The loop body cyclegan.py:159-180.  Losses come back as 1-element device tensors."""
         real_A, real_B = self.split(real_data)
         # Forward G network
-        fake_A, fake_B = self.forward_fakes(real_data)
+        fake_A, fake_B = self.forward_fakes(real_data, keep=True)
         [fake_A, fake_B] = self.pool([fake_A, fake_B])
         out = {}
         # Update D network
@@ -181,6 +210,7 @@ class CycleGAN(object):
         out['da_loss_real'], out['da_loss_fake'] = r, f
         # Update G network
         out['g_b2a_gan'], out['g_b2a_cyc_a'], out['g_b2a_cyc_b'] = self.g_update('b2a', real_data)
+        self._kept = {}
         return out
 
     @staticmethod

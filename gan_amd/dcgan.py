@@ -212,7 +212,7 @@ class DCGAN(object):
             self.d_optim.begin()
             self._g_pass = None
             if keep_g:
-                with ops.moving_update_log() as log:
+                with ops.moving_update_log() as log, ops.taping():
                     G_taped = self.generator(z, y)
                 self._g_pass = (G_taped, log, z, y)
                 G = G_taped.detach()                           # gradients stop at d_vars
@@ -225,7 +225,7 @@ class DCGAN(object):
                 both = ops.stack_batches(images, G)
                 y2 = None if y is None else ops.stack_batches(y, y)
                 _, logits = self.discriminator(both, y2, reuse=True, passes=2, with_prob=False)
-                d_loss_real, d_loss_fake = ops.stacked_sigmoid_cross_entropy_means(logits, 1.0, 0.0)
+                d_loss_real, d_loss_fake = ops.stacked_sigmoid_cross_entropy_means(logits, (1.0, 0.0))
             else:
                 _, D_logits = self.discriminator(images, y, reuse=False)
                 _, D_logits_ = self.discriminator(G, y, reuse=True)

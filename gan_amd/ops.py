@@ -36,9 +36,27 @@ variable_scope = V.variable_scope
 _token = {}
 
 
-def _grad_token(device):
-    """A leaf that requires grad, threaded through every layer so that the layer's backward runs
-    (and can emit weight gradients) even when its data input needs no gradient."""
+_force_tape = [False]
+
+
+class taping(object):
+    """Inside the block every layer records its backward, also layers whose weights are not being
+    updated right now and whose input needs no gradient (a pass that a later update will reuse)."""
+
+    def __enter__(self):
+        self.previous, _force_tape[0] = _force_tape[0], True
+
+    def __exit__(self, *exc):
+        _force_tape[0] = self.previous
+
+
+def _grad_token(device, var=None):
+    """A leaf that requires grad, threaded through a layer so that its backward runs (and can emit
+    weight gradients) even when its data input needs no gradient.  Layers whose weights are frozen
+    in the current update get none: with a no-gradient input they drop out of the backward pass
+    (tf.gradients prunes the same sub-graph, e.g. G_B2A(real_B) in cyclegan.py's g_loss_a2b)."""
+    if var is not None and not var.wants_grad and not _force_tape[0]:
+        return None
     t = _token.get(device)
     if t is None:
         t = torch.zeros(1, device=device, requires_grad=True)
@@ -208,7 +226,7 @@ def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding=
     g = _conv_geom(n, h, w_, cin, output_dim, k_h, k_w, d_h, d_w, padding)
     if autotune.enabled():
         autotune.tune_geometry(g)
-    return _Conv2dFn.apply(input_, _grad_token(input_.device), w, biases, g)
+    return _Conv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g)
 
 
 def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="deconv2d", with_w=False):
@@ -225,7 +243,7 @@ def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name
     g = _conv_geom(n, oh, ow, oc, cin, k_h, k_w, d_h, d_w, 'SAME', small_hw=(hs, ws))
     if autotune.enabled():
         autotune.tune_geometry(g)
-    deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device), w, biases, g)
+    deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g)
     if with_w:
         return deconv, w, biases
     return deconv
@@ -241,7 +259,7 @@ def linear(input_, output_size, scope_name=None, stddev=0.02, bias_start=0.0, wi
         bias = st.get_variable("bias", [output_size], V.constant_initializer(bias_start))
     if autotune.enabled():
         autotune.tune_linear(int(input_.shape[0]), int(input_.shape[1]), int(output_size))
-    y = _LinearFn.apply(input_, _grad_token(input_.device), matrix, bias)
+    y = _LinearFn.apply(input_, _grad_token(input_.device, matrix), matrix, bias)
     if with_w:
         return y, matrix, bias
     return y
@@ -349,7 +367,7 @@ class batch_norm(object):
         if train:
             if x.shape[0] % passes:
                 raise ValueError("batch_norm: batch of %d does not split into %d passes" % (x.shape[0], passes))
-            return _NormFn.apply(x, residual, _grad_token(x.device), gamma, beta, mm, mv, int(passes), float(self.epsilon),
+            return _NormFn.apply(x, residual, _grad_token(x.device, gamma), gamma, beta, mm, mv, int(passes), float(self.epsilon),
                                  float(self.momentum), self.unbiased_moving_var, code, float(act_param))
         if residual is not None:
             raise ValueError("batch_norm(train=False) does not take a residual")
@@ -371,7 +389,7 @@ def instance_norm(x, name="instance_norm", epsilon=1e-5, act=None, act_param=0.2
     with st.variable_scope(name):
         beta = st.get_variable('beta', [c], V.constant_initializer(0.0))
         gamma = st.get_variable('gamma', [c], V.constant_initializer(1.0))
-    return _NormFn.apply(x, None, _grad_token(x.device), gamma, beta, None, None, int(x.shape[0]), float(epsilon),
+    return _NormFn.apply(x, None, _grad_token(x.device, gamma), gamma, beta, None, None, int(x.shape[0]), float(epsilon),
                          0.0, False, ACT_CODES[act], float(act_param))
 
 
@@ -547,42 +565,46 @@ def sigmoid_cross_entropy_mean(logits, label, weight=1.0):
 
 
 class _StackedBceFn(torch.autograd.Function):
-    """Two sigmoid cross-entropy means over the two halves of a stacked batch of logits."""
+    """One sigmoid cross-entropy mean per part of a stack of equally sized batches of logits."""
 
     @staticmethod
-    def forward(ctx, logits, label_a, label_b, weight):
+    def forward(ctx, logits, labels, weight):
         x = _dense(logits)
-        n = x.numel() // 2
-        la = torch.empty(1, dtype=torch.float32, device=x.device)
-        lb = torch.empty(1, dtype=torch.float32, device=x.device)
+        k = len(labels)
+        n = x.numel() // k
+        losses = [torch.empty(1, dtype=torch.float32, device=x.device) for _ in range(k)]
         grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gp = ptr(grad)
-        check(lib.gan_sigmoid_bce_mean(ptr(x), n, label_a, weight, 0, ptr(la), gp, stream()))
-        check(lib.gan_sigmoid_bce_mean(ptr(x) + 4 * n, n, label_b, weight, 0, ptr(lb),
-                                       None if gp is None else gp + 4 * n, stream()))
+        for i, label in enumerate(labels):
+            check(lib.gan_sigmoid_bce_mean(ptr(x) + 4 * n * i, n, label, weight, 0, ptr(losses[i]),
+                                           None if gp is None else gp + 4 * n * i, stream()))
         ctx.grad = grad
-        return la, lb
+        return tuple(losses)
 
     @staticmethod
-    def backward(ctx, _one_a, _one_b):
-        return ctx.grad, None, None, None
+    def backward(ctx, *_ones):
+        return ctx.grad, None, None
 
 
-def stacked_sigmoid_cross_entropy_means(logits, label_first, label_second, weight=1.0):
-    """(mean CE of the first half against label_first, mean CE of the second half against
-    label_second) of logits that hold two stacked batches; both are roots for backward()."""
-    if logits.shape[0] % 2:
-        raise ValueError("stacked logits need an even batch, got %d" % logits.shape[0])
-    return _StackedBceFn.apply(logits, float(label_first), float(label_second), float(weight))
+def stacked_sigmoid_cross_entropy_means(logits, labels, weight=1.0):
+    """Mean cross entropy of each of the len(labels) equal parts of `logits` (batches stacked along
+    axis 0) against its constant label; every returned loss is a root for backward()."""
+    labels = tuple(float(v) for v in labels)
+    if logits.shape[0] % len(labels):
+        raise ValueError("stacked logits: batch of %d does not split into %d parts" % (logits.shape[0], len(labels)))
+    return _StackedBceFn.apply(logits, labels, float(weight))
 
 
-def stack_batches(a, b):
-    """[a; b] along axis 0 in one new buffer (two device copies)."""
-    if a.shape != b.shape:
-        raise ValueError("stack_batches: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
-    out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
-    out[:a.shape[0]].copy_(a.detach())
-    out[a.shape[0]:].copy_(b.detach())
+def stack_batches(*parts):
+    """[a; b; ...] along axis 0 in one new buffer (one device copy per part)."""
+    a = parts[0]
+    for b in parts[1:]:
+        if a.shape != b.shape:
+            raise ValueError("stack_batches: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
+    n = a.shape[0]
+    out = torch.empty((len(parts) * n,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    for i, t in enumerate(parts):
+        out[i * n:(i + 1) * n].copy_(t.detach())
     return out
 
 

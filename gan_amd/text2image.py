@@ -64,6 +64,7 @@ class Text2Image(object):
         self.data_dir = getattr(options, 'data_dir', 'data')
         self.save_every_batch = getattr(options, 'save_every_batch', 50)
         self.world_size, self.process_group = world_size, process_group
+        self.stack_d_passes = True      # D update: the three D applications as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
 
         self.g_bn0 = ops.batch_norm(name='g_bn0')
@@ -140,70 +141,100 @@ class Text2Image(object):
             return ops.tanh(h4, scale=0.5, shift=0.5)      # tf.tanh(h4)/2. + 0.5
 
     # DISCRIMINATOR (text2image.py:201-222)
-    def discriminator(self, image, t_text_embedding, reuse=False):
+    def discriminator(self, image, t_text_embedding, reuse=False, passes=1, with_prob=True):
+        """passes=k: `image` and `t_text_embedding` hold k batches stacked along axis 0 and the call
+        stands for k applications of the network (shared weights, batch-norm statistics per batch).
+        with_prob=False skips the sigmoid of the first return value (None then)."""
+        bs = self.batch_size * passes
         with ops.variable_scope("discriminator") as scope:
             if reuse:
                 scope.reuse_variables()
 
-            h0 = ops.lrelu(ops.conv2d(image, self.df_dim, name='d_h0_conv'))                        # 32
-            h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu')          # 16
-            h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu')          # 8
-            h3 = self.d_bn3(ops.conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu')          # 4
+            h0 = ops.lrelu(ops.conv2d(image, self.df_dim, name='d_h0_conv'))                                       # 32
+            h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)         # 16
+            h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)         # 8
+            h3 = self.d_bn3(ops.conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu', passes=passes)         # 4
 
             # ADD TEXT EMBEDDING TO THE NETWORK: expand_dims x2 + tile [1,4,4,1] + concat on channels
             reduced_text_embeddings = ops.lrelu(ops.linear(t_text_embedding, self.t_dim, 'd_embedding'))
-            h3_concat = ops.conv_cond_concat(h3, reduced_text_embeddings.reshape(self.batch_size, 1, 1, self.t_dim))
-            h3_new = self.d_bn4(ops.conv2d(h3_concat, self.df_dim * 8, 1, 1, 1, 1, name='d_h3_conv_new'), act='lrelu')  # 4
+            h3_concat = ops.conv_cond_concat(h3, reduced_text_embeddings.reshape(bs, 1, 1, self.t_dim))
+            h3_new = self.d_bn4(ops.conv2d(h3_concat, self.df_dim * 8, 1, 1, 1, 1, name='d_h3_conv_new'), act='lrelu',
+                                passes=passes)                                                                     # 4
 
-            h4 = ops.linear(h3_new.reshape(self.batch_size, -1), 1, 'd_h3_lin')
-            with torch.no_grad():
-                prob = ops.sigmoid(h4.detach())
+            h4 = ops.linear(h3_new.reshape(bs, -1), 1, 'd_h3_lin')
+            prob = None
+            if with_prob:
+                with torch.no_grad():
+                    prob = ops.sigmoid(h4.detach())
             return prob, h4
 
     # ---------------------------------------------------------------------------------- updates
-    def d_grads(self, real_image, wrong_image, real_caption, z):
-        """d_loss = d_loss1 + d_loss2 + d_loss3 (text2image.py:88-92) and its gradient w.r.t. d_vars."""
+    def d_grads(self, real_image, wrong_image, real_caption, z, keep_g=False):
+        """d_loss = d_loss1 + d_loss2 + d_loss3 (text2image.py:88-92) and its gradient w.r.t. d_vars.
+        The three discriminator applications (real, wrong, fake image with the same captions) run
+        as one stacked batch with per-application batch-norm statistics.  keep_g=True records the
+        generator pass for the next g_grads(reuse_g=True), as in DCGAN.d_grads."""
         with V.use_store(self.store):
             self.d_optim.begin()
-            with torch.no_grad():
-                fake_image = self.generator(z, real_caption)
-            _, real_logits = self.discriminator(real_image, real_caption)
-            _, wrong_logits = self.discriminator(wrong_image, real_caption, reuse=True)
-            _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True)
-            d_loss1 = ops.sigmoid_cross_entropy_mean(real_logits, 1.0)
-            d_loss2 = ops.sigmoid_cross_entropy_mean(wrong_logits, 0.0)
-            d_loss3 = ops.sigmoid_cross_entropy_mean(fake_logits, 0.0)
+            self._g_pass = None
+            if keep_g:
+                with ops.moving_update_log() as log, ops.taping():
+                    taped = self.generator(z, real_caption)
+                self._g_pass = (taped, log, z, real_caption)
+                fake_image = taped.detach()
+            else:
+                with torch.no_grad():
+                    fake_image = self.generator(z, real_caption)
+            if self.stack_d_passes:
+                images = ops.stack_batches(real_image, wrong_image, fake_image)
+                captions = ops.stack_batches(real_caption, real_caption, real_caption)
+                _, logits = self.discriminator(images, captions, reuse=True, passes=3, with_prob=False)
+                d_loss1, d_loss2, d_loss3 = ops.stacked_sigmoid_cross_entropy_means(logits, (1.0, 0.0, 0.0))
+            else:
+                _, real_logits = self.discriminator(real_image, real_caption)
+                _, wrong_logits = self.discriminator(wrong_image, real_caption, reuse=True)
+                _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True)
+                d_loss1 = ops.sigmoid_cross_entropy_mean(real_logits, 1.0)
+                d_loss2 = ops.sigmoid_cross_entropy_mean(wrong_logits, 0.0)
+                d_loss3 = ops.sigmoid_cross_entropy_mean(fake_logits, 0.0)
             ops.backward([d_loss1, d_loss2, d_loss3])
             self.d_optim.finish_grads()
         return d_loss1.detach(), d_loss2.detach(), d_loss3.detach(), fake_image
 
-    def g_grads(self, real_caption, z):
-        """g_loss (text2image.py:86) and its gradient w.r.t. g_vars."""
+    def g_grads(self, real_caption, z, reuse_g=False):
+        """g_loss (text2image.py:86) and its gradient w.r.t. g_vars.  reuse_g=True takes the
+        generator pass the preceding d_grads(keep_g=True) recorded (same z, captions and generator
+        weights: text2image.py:251-265 evaluates it twice) and replays its moving-average updates."""
         with V.use_store(self.store):
             self.g_optim.begin()
-            fake_image = self.generator(z, real_caption)
-            _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True)
+            kept, self._g_pass = getattr(self, '_g_pass', None), None
+            if reuse_g and kept is not None and kept[2] is z and kept[3] is real_caption:
+                fake_image = kept[0]
+                kept[1].replay()
+            else:
+                fake_image = self.generator(z, real_caption)
+            _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True, with_prob=False)
             g_loss = ops.sigmoid_cross_entropy_mean(fake_logits, 1.0)
             ops.backward(g_loss)
             self.g_optim.finish_grads()
         return g_loss.detach(), fake_image.detach()
 
-    def d_update(self, real_image, wrong_image, real_caption, z):
-        out = self.d_grads(real_image, wrong_image, real_caption, z)
+    def d_update(self, real_image, wrong_image, real_caption, z, keep_g=False):
+        out = self.d_grads(real_image, wrong_image, real_caption, z, keep_g=keep_g)
         self.d_optim.all_reduce(self.world_size, self.process_group)
         self.d_optim.adam(self.world_size)
         return out
 
-    def g_update(self, real_caption, z):
-        out = self.g_grads(real_caption, z)
+    def g_update(self, real_caption, z, reuse_g=False):
+        out = self.g_grads(real_caption, z, reuse_g=reuse_g)
         self.g_optim.all_reduce(self.world_size, self.process_group)
         self.g_optim.adam(self.world_size)
         return out
 
     def train_iteration(self, real_image, wrong_image, real_caption, z):
         """One batch of text2image.py:249-276: DISCR UPDATE, GEN UPDATE, GEN UPDATE TWICE."""
-        d1, d2, d3, _ = self.d_update(real_image, wrong_image, real_caption, z)
-        g1, _ = self.g_update(real_caption, z)
+        d1, d2, d3, _ = self.d_update(real_image, wrong_image, real_caption, z, keep_g=True)
+        g1, _ = self.g_update(real_caption, z, reuse_g=True)
         g2, gen = self.g_update(real_caption, z)
         return {'d_loss1': d1, 'd_loss2': d2, 'd_loss3': d3, 'g_loss_1': g1, 'g_loss_2': g2, 'generator': gen}
 

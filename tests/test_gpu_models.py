@@ -314,3 +314,52 @@ def test_batch_norm_stacked_passes_equal_separate_calls():
                     host(st.vars['bn/moving_mean'].data), host(st.vars['bn/moving_variance'].data)))
     for got, want, what in zip(res[1], res[0], ("y", "dx", "dgamma", "dbeta", "moving_mean", "moving_variance")):
         assert_close(got, want, "stacked batch_norm " + what, tol=1e-6)
+
+
+def test_cyclegan_shared_generator_passes_equal_run_by_run():
+    """train_iteration keeps the generator passes of the first run for the generator updates and
+    prunes the backward of frozen sub-graphs; the trained values are those of five independent runs."""
+    from gan_amd.cyclegan import CycleGAN
+    _, a, rng, o = cyc_pair(seed=35)
+    _, b, _, _ = cyc_pair(seed=35)
+    for _ in range(2):
+        real = dev(rng.uniform(-1, 1, (1, o.fine_size, o.fine_size, 6)))
+        ta = CycleGAN.totals(a.train_iteration(real))
+        rA, rB = b.split(real)
+        fA, fB = b.forward_fakes(real)                      # nothing kept: every run recomputes
+        out = {}
+        out['db_loss_real'], out['db_loss_fake'] = b.d_update('B', rB, fB)
+        out['g_a2b_gan'], out['g_a2b_cyc_a'], out['g_a2b_cyc_b'] = b.g_update('a2b', real)
+        out['da_loss_real'], out['da_loss_fake'] = b.d_update('A', rA, fA)
+        out['g_b2a_gan'], out['g_b2a_cyc_a'], out['g_b2a_cyc_b'] = b.g_update('b2a', real)
+        tb = CycleGAN.totals(out)
+        torch.cuda.synchronize()
+        assert ta == tb
+    for name, v in a.store.vars.items():
+        w = b.store.vars[name]
+        if 'moving_' in name:
+            torch.testing.assert_close(v.data, w.data, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(v.data, w.data), name
+
+
+def test_text2image_shared_pass_and_stacked_d_equal_separate_runs():
+    _, a, rng, o = t2i_pair(seed=25)
+    _, b, _, _ = t2i_pair(seed=25)
+    b.stack_d_passes = False
+    for _ in range(2):
+        real, wrong, cap, z = [dev(t) for t in t2i_batch(rng, o)]
+        oa = a.train_iteration(real, wrong, cap, z)
+        d1, d2, d3, _ = b.d_update(real, wrong, cap, z)
+        g1, _ = b.g_update(cap, z)
+        g2, _ = b.g_update(cap, z)
+        torch.cuda.synchronize()
+        for got, want in zip((oa['d_loss1'], oa['d_loss2'], oa['d_loss3'], oa['g_loss_1'], oa['g_loss_2']),
+                             (d1, d2, d3, g1, g2)):
+            assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    for name, v in a.store.vars.items():      # stacked vs separate D passes differ in summation order only
+        w = b.store.vars[name]
+        if name.endswith(('/biases', '/bias')):
+            continue                           # rounding-noise gradients under Adam
+        # Adam moves an element whose gradient is rounding noise by up to lr per update: 6 updates of 2e-4
+        torch.testing.assert_close(v.data, w.data, rtol=2e-3, atol=1.5e-3)
