@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None, help="layer:pass, e.g. d_h1:fwd")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--autotune", action="store_true", help="pin the tuned plan of each layer before timing it")
     ap.add_argument("--cfg", default=None)
     ap.add_argument("--splits", default=None)
     args = ap.parse_args()
@@ -68,6 +69,9 @@ def main():
     for lname, (n, h, w_, cb, cs, k, s) in LAYERS:
         n = args.batch
         g = ops._conv_geom(n, h, w_, cb, cs, k, k, s, s, 'SAME')
+        if args.autotune:
+            from gan_amd import autotune
+            autotune.tune_geometry(g)
         big = torch.randn(n, h, w_, cb, device='cuda')
         small = torch.randn(n, g.hs, g.ws, cs, device='cuda')
         w = torch.randn(k, k, cb, cs, device='cuda') * 0.05
