@@ -42,6 +42,11 @@ SMALL_CONVS = [
     (3, 28, 28, 1, 16, 5, 2, 'SAME'),
     (2, 12, 12, 4, 16, 3, 2, 'SAME'),
     (2, 70, 41, 3, 48, 5, 2, 'SAME'),      # several 8x32 patches per class, ragged edges
+    # thin big side with >= 4096 small-side pixels: the vector-ALU weight-gradient path
+    (2, 96, 100, 3, 64, 5, 2, 'SAME'),
+    (1, 70, 74, 3, 24, 7, 1, 'VALID'),     # 7x7 stem, cs not a multiple of 64
+    (2, 90, 90, 1, 130, 5, 2, 'SAME'),     # cb = 1, three channel chunks, ragged last chunk
+    (1, 68, 70, 4, 18, 3, 1, 'SAME'),      # cs % 4 != 0: scalar staging and reduction
 ]
 
 DCGAN_CONVS = [
