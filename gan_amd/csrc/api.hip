@@ -115,6 +115,100 @@ extern "C" int gan_deconv2d_wgrad(const gan_conv_geom* g, const float* x, const 
     return 0;
 }
 
+// ---------------------------------------------------------------------------- thin linear
+// ops.linear onto a handful of outputs (the discriminator's final logit: 8192 -> 1) is three
+// matrix-vector products; the 32-wide MFMA tile would be almost all padding.  They are plain
+// bandwidth kernels instead.  OUT <= 4.
+namespace gan {
+
+constexpr int kThinLinMaxOut = 4;
+
+// y[r][o] = sum_i x[r][i] * w[i][o] + bias[o]; one block per row
+template <int OUT>
+__global__ __launch_bounds__(256) void linear_thin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int in_dim) {
+    __shared__ float red[4][OUT];
+    const int r = blockIdx.x;
+    const float* xr = x + (long)r * in_dim;
+    float acc[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) acc[o] = 0.f;
+    for (int i = threadIdx.x; i < in_dim; i += 256) {
+        const float xv = xr[i];
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(xv, w[(long)i * OUT + o], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+        const float v = wave_sum(acc[o]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < OUT) {
+        const int o = threadIdx.x;
+        y[(long)r * OUT + o] = red[0][o] + red[1][o] + red[2][o] + red[3][o] + (bias ? bias[o] : 0.f);
+    }
+}
+
+// dx[r][i] = sum_o dy[r][o] * w[i][o]
+template <int OUT>
+__global__ void linear_thin_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                         int rows, int in_dim) {
+    const long total = (long)rows * in_dim;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / in_dim), i = (int)(e - (long)r * in_dim);
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) v = fmaf(dy[(long)r * OUT + o], w[(long)i * OUT + o], v);
+        dx[e] = v;
+    }
+}
+
+// dw[i][o] (+)= sum_r x[r][i] * dy[r][o]; db[o] (+)= sum_r dy[r][o].  One thread per input index,
+// rows summed in order.
+template <int OUT>
+__global__ __launch_bounds__(256) void linear_thin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                float* __restrict__ dw, float* __restrict__ db, int rows,
+                                                                int in_dim, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < in_dim) {
+        float acc[OUT];
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < rows; ++r) {
+            const float xv = x[(long)r * in_dim + i];
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) acc[o] = fmaf(xv, dy[(long)r * OUT + o], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) {
+            float* d = dw + (long)i * OUT + o;
+            *d = (accumulate ? *d : 0.f) + acc[o];
+        }
+    }
+    if (db != nullptr && blockIdx.x == 0 && threadIdx.x < OUT) {
+        float sum = 0.f;
+        for (int r = 0; r < rows; ++r) sum += dy[(long)r * OUT + threadIdx.x];
+        db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + sum;
+    }
+}
+
+static bool thin_linear_ok(int in_dim, int out_dim) {
+    return out_dim <= kThinLinMaxOut && in_dim >= 256 && getenv("GAN_HIP_NO_THIN") == nullptr;
+}
+
+#define GAN_THIN_LIN_DISPATCH(KERNEL, GRID, BLOCK, ...)                                            \
+    switch (out_dim) {                                                                             \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, 0, st, __VA_ARGS__); break;             \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, 0, st, __VA_ARGS__); break;             \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, BLOCK, 0, st, __VA_ARGS__); break;             \
+        default: hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, 0, st, __VA_ARGS__); break;            \
+    }
+
+}  // namespace gan
+
 static int linear_check(const char* what, int rows, int in_dim, int out_dim) {
     GAN_CHECK_ARG(rows > 0 && in_dim > 0 && out_dim > 0, "%s: rows, in_dim and out_dim must be positive", what);
     return 0;
@@ -130,6 +224,11 @@ extern "C" int gan_linear_fwd(int rows, int in_dim, int out_dim, const float* x,
                               const float* bias, float* y, void* ws, size_t ws_bytes, gan_stream_t stream) {
     if (int rc = linear_check("gan_linear_fwd", rows, in_dim, out_dim)) return rc;
     GAN_CHECK_ARG(x && matrix && y, "gan_linear_fwd: NULL tensor");
+    if (thin_linear_ok(in_dim, out_dim)) {
+        hipStream_t st = as_stream(stream);
+        GAN_THIN_LIN_DISPATCH(linear_thin_fwd_kernel, dim3(rows), dim3(256), x, matrix, bias, y, in_dim);
+        return check_launch("gan_linear_fwd");
+    }
     return run_igemm_geom(MODE_FPROP, linear_geom(rows, in_dim, out_dim), x, matrix, y, bias, 0, out_dim, ws, ws_bytes,
                           as_stream(stream), "gan_linear_fwd");
 }
@@ -138,6 +237,13 @@ extern "C" int gan_linear_dgrad(int rows, int in_dim, int out_dim, const float* 
                                 void* ws, size_t ws_bytes, gan_stream_t stream) {
     if (int rc = linear_check("gan_linear_dgrad", rows, in_dim, out_dim)) return rc;
     GAN_CHECK_ARG(dy && matrix && dx, "gan_linear_dgrad: NULL tensor");
+    if (thin_linear_ok(in_dim, out_dim)) {
+        hipStream_t st = as_stream(stream);
+        long blocks = ((long)rows * in_dim + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        GAN_THIN_LIN_DISPATCH(linear_thin_dgrad_kernel, dim3((unsigned)blocks), dim3(256), dy, matrix, dx, rows, in_dim);
+        return check_launch("gan_linear_dgrad");
+    }
     return run_igemm_geom(MODE_TPROP, linear_geom(rows, in_dim, out_dim), dy, matrix, dx, nullptr, 0, in_dim, ws, ws_bytes,
                           as_stream(stream), "gan_linear_dgrad");
 }
@@ -146,6 +252,12 @@ extern "C" int gan_linear_wgrad(int rows, int in_dim, int out_dim, const float* 
                                 float* dbias, int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream) {
     if (int rc = linear_check("gan_linear_wgrad", rows, in_dim, out_dim)) return rc;
     GAN_CHECK_ARG(x && dy && dmatrix, "gan_linear_wgrad: NULL tensor");
+    if (thin_linear_ok(in_dim, out_dim)) {
+        hipStream_t st = as_stream(stream);
+        GAN_THIN_LIN_DISPATCH(linear_thin_wgrad_kernel, dim3((in_dim + 255) / 256), dim3(256), x, dy, dmatrix, dbias, rows,
+                              in_dim, accumulate);
+        return check_launch("gan_linear_wgrad");
+    }
     if (int rc = run_igemm_geom(MODE_WGRAD, linear_geom(rows, in_dim, out_dim), x, dy, dmatrix, nullptr, accumulate, out_dim,
                                 ws, ws_bytes, as_stream(stream), "gan_linear_wgrad"))
         return rc;

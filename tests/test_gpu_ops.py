@@ -197,7 +197,9 @@ def test_deconv2d_is_adjoint_of_conv2d_on_device(L):
 
 
 @pytest.mark.parametrize("rows,i,o", [(64, 100, 8192), (64, 8192, 1), (64, 110, 1024), (64, 1034, 6272),
-                                      (64, 3636, 1024), (5, 7, 3), (64, 1024, 256)])
+                                      (64, 3636, 1024), (5, 7, 3), (64, 1024, 256),
+                                      # a handful of outputs: the matrix-vector kernels
+                                      (64, 1034, 1), (128, 8192, 1), (9, 300, 3), (7, 513, 4), (8, 256, 2)])
 def test_linear(L, rows, i, o):
     from gpu_util import assert_close, dev, host
     x = RNG.standard_normal((rows, i)).astype(np.float32)
@@ -219,6 +221,11 @@ def test_linear(L, rows, i, o):
     assert_close(host(dx), dx_ref, "linear dgrad")
     assert_close(host(dm), dm_ref, "linear wgrad")
     assert_close(host(db), db_ref, "linear bias grad")
+    # accumulate: a second call adds onto what is there
+    L.check(L.lib.gan_linear_wgrad(rows, i, o, L.ptr(xd), L.ptr(dyd), L.ptr(dm), L.ptr(db), 1, wp, wn, st))
+    torch.cuda.synchronize()
+    assert_close(host(dm), 2 * dm_ref, "linear wgrad accumulate")
+    assert_close(host(db), 2 * db_ref, "linear bias grad accumulate")
 
 
 ACTS = [(0, 0.0), (1, 0.0), (2, 0.2), (3, 0.0), (4, 0.0)]
