@@ -222,13 +222,24 @@ class CycleGAN(object):
                 'da_loss': f('da_loss_real') + f('da_loss_fake'),
                 'g_loss_b2a': f('g_b2a_gan') + f('g_b2a_cyc_a') + f('g_b2a_cyc_b')}
 
-    def train(self, dataA, dataB, max_iters=None, seed=0):
-        """cyclegan.py:137-190 for in-memory data: dataA / dataB are [N, s, s, c] float arrays in
-        [-1, 1] (what load_data yields, misc.py:288-289); both are shuffled every epoch and paired
-        by position, batches are the channel-wise concatenation real_A | real_B."""
+    def train(self, dataA=None, dataB=None, max_iters=None, seed=0, sample_every=100):
+        """cyclegan.py:137-190.  dataA / dataB are lists of image files (default: the reference's
+        ./<data_dir>/<dataset>/trainA|trainB/*.jpg, loaded with misc.load_data: resize to load_size,
+        random crop to fine_size, random flip) or in-memory [N, s, s, c] float arrays in [-1, 1].
+        Both are shuffled every epoch and paired by position; a batch is real_A | real_B on the
+        channel axis.  Every `sample_every` iterations the translations of the current batch go to
+        opts.sample_dir (sample_model, :216-236; 0 disables it)."""
+        from glob import glob
+        from .misc import load_data, save_images
         opts = self.options
         dev = self.store.device
         rng = np.random.RandomState(seed)
+        if dataA is None:
+            dataA = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/trainA')))
+            dataB = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/trainB')))
+        if len(dataA) == 0 or len(dataB) == 0:
+            raise RuntimeError("no training data under %s/trainA and %s/trainB" % (self.dataset_dir, self.dataset_dir))
+        from_files = isinstance(dataA[0], str)
         counter = 1
         start_time = time.time()
         if self.load(opts.checkpoint_dir):
@@ -236,21 +247,35 @@ class CycleGAN(object):
         else:
             print(" [!] Load failed...")
         iters = 0
+        out = None
         for epoch in range(opts.nEpochs):
             ia, ib = rng.permutation(len(dataA)), rng.permutation(len(dataB))
             batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // self.batch_size
             for idx in range(0, batch_idxs):
                 sl = slice(idx * self.batch_size, (idx + 1) * self.batch_size)
-                batch = np.concatenate([np.asarray(dataA)[ia[sl]], np.asarray(dataB)[ib[sl]]], axis=3).astype(np.float32)
-                out = self.train_iteration(torch.from_numpy(batch).to(dev))
+                if from_files:
+                    batch = np.array([load_data((dataA[a], dataB[b]), flip=getattr(opts, 'flip', True),
+                                                load_size=getattr(opts, 'load_size', 286), fine_size=self.image_size, rng=rng)
+                                      for a, b in zip(ia[sl], ib[sl])]).astype(np.float32)
+                else:
+                    batch = np.concatenate([np.asarray(dataA)[ia[sl]], np.asarray(dataB)[ib[sl]]], axis=3).astype(np.float32)
+                real = torch.from_numpy(batch).to(dev)
+                out = self.train_iteration(real)
                 counter += 1
                 print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
+                if sample_every and np.mod(counter, sample_every) == 1:
+                    fake_A, fake_B = self.forward_fakes(real)
+                    sample_dir = getattr(opts, 'sample_dir', './samples')
+                    if not os.path.exists(sample_dir):
+                        os.makedirs(sample_dir)
+                    save_images(fake_A.cpu().numpy(), [self.batch_size, 1], '{}/A_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
+                    save_images(fake_B.cpu().numpy(), [self.batch_size, 1], '{}/B_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
                 if np.mod(counter, 1000) == 2:
                     self.save(opts.checkpoint_dir, counter)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
                     return out
-        return None
+        return out
 
     def test(self, images, which_direction='AtoB'):
         """cyclegan.py:238-265 without the file I/O: translate a batch with one generator."""

@@ -336,16 +336,39 @@ class DCGAN(object):
         return run
 
     # ------------------------------------------------------------------------------------ train loop
-    def train(self, data_X=None, data_y=None, max_iters=None):
-        """dcgan.py:151-320 for in-memory data ([N,H,W,C] float array in the network's input range
-        and, for the conditional model, one-hot labels)."""
+    def _load_files(self, files):
+        """dcgan.py:210-221: centre-crop / resize / scale a list of image files to one NHWC batch."""
+        from .misc import get_image
+        batch = [get_image(f, input_height=self.input_height, input_width=self.input_width,
+                           resize_height=self.output_height, resize_width=self.output_width, crop=self.crop,
+                           grayscale=self.grayscale) for f in files]
+        arr = np.array(batch).astype(np.float32)
+        return arr[:, :, :, None] if self.grayscale else arr
+
+    def train(self, data_X=None, data_y=None, max_iters=None, data_files=None, sample_every=100):
+        """dcgan.py:151-320.  Data comes from in-memory arrays ([N,H,W,C] in the network's input
+        range, plus one-hot labels for the conditional model: MNIST via load_mnist), or from image
+        files: `data_files`, else ./data/<dataset>/<input_fname_pattern> as in the reference
+        (:200-201).  Every `sample_every` iterations a grid of sampler outputs is written to
+        opts.sample_dir (:287-317; 0 disables it)."""
+        from glob import glob
+        from .misc import save_images
         opts = self.opts
-        if data_X is None:
+        if data_X is None and data_files is None:
             data_X, data_y = self.data_X, self.data_y
-        if data_X is None:
-            raise RuntimeError("no training data: pass data_X (and data_y) or place MNIST under ./data/mnist")
+        if data_X is None and data_files is None and opts.dataset != 'mnist':
+            data_files = sorted(glob(os.path.join("./data", opts.dataset, self.input_fname_pattern)))
+        if data_X is None and not data_files:
+            raise RuntimeError("no training data: pass data_X (and data_y) or data_files, or place MNIST under "
+                               "./data/mnist / images under ./data/%s" % opts.dataset)
         dev = self.store.device
         rng = np.random.RandomState(getattr(opts, 'seed', 0))
+        sample_num = min(self.batch_size, 64)
+        sample_z = torch.from_numpy(rng.uniform(-1, 1, size=(self.batch_size, self.z_dim)).astype(np.float32)).to(dev)
+        sample_y = None
+        if self.y_dim and data_y is not None:
+            sample_y = torch.from_numpy(np.asarray(data_y[:self.batch_size], dtype=np.float32)).to(dev)
+        sample_dir = getattr(opts, 'sample_dir', './samples')
         start_time = time.time()
         could_load, checkpoint_counter = self.load(self.checkpoint_dir)
         if could_load:
@@ -355,14 +378,16 @@ class DCGAN(object):
             print(" [!] Load failed...")
         iters = 0
         for epoch in range(opts.nEpochs):
-            batch_idxs = int(min(len(data_X), opts.train_size)) // opts.batch_size
+            n_items = len(data_X) if data_X is not None else len(data_files)
+            batch_idxs = int(min(n_items, opts.train_size)) // opts.batch_size
             for idx in range(0, batch_idxs):
-                batch_images = torch.from_numpy(
-                    np.asarray(data_X[idx * opts.batch_size:(idx + 1) * opts.batch_size], dtype=np.float32)).to(dev)
+                sl = slice(idx * opts.batch_size, (idx + 1) * opts.batch_size)
+                host_batch = (np.asarray(data_X[sl], dtype=np.float32) if data_X is not None
+                              else self._load_files(data_files[sl]))
+                batch_images = torch.from_numpy(host_batch).to(dev)
                 batch_labels = None
                 if self.y_dim:
-                    batch_labels = torch.from_numpy(
-                        np.asarray(data_y[idx * opts.batch_size:(idx + 1) * opts.batch_size], dtype=np.float32)).to(dev)
+                    batch_labels = torch.from_numpy(np.asarray(data_y[sl], dtype=np.float32)).to(dev)
                 batch_z = torch.from_numpy(
                     rng.uniform(-1, 1, [opts.batch_size, self.z_dim]).astype(np.float32)).to(dev)
                 log = (idx % self.print_every == 0)
@@ -372,6 +397,14 @@ class DCGAN(object):
                     print("Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f"
                           % (epoch, idx, batch_idxs, time.time() - start_time,
                              float(out['errD_fake']) + float(out['errD_real']), float(out['errG'])))
+                if sample_every and np.mod(self.counter, sample_every) == 1 and (not self.y_dim or sample_y is not None):
+                    samples = self.sampler(sample_z, sample_y).cpu().numpy()[:sample_num]
+                    manifold_h = int(np.ceil(np.sqrt(samples.shape[0])))
+                    manifold_w = int(np.floor(np.sqrt(samples.shape[0])))
+                    if not os.path.exists(sample_dir):
+                        os.makedirs(sample_dir)
+                    save_images(samples[:manifold_h * manifold_w], [manifold_h, manifold_w],
+                                os.path.join(sample_dir, 'train_{:02d}_{:04d}.png'.format(epoch, idx)))
                 if np.mod(self.counter, 500) == 2:
                     self.save(opts.checkpoint_dir, self.counter)
                 iters += 1

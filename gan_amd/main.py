@@ -185,12 +185,12 @@ def main(opts):
     if opts.phase == 'train':
         if opts.synthetic_iters:
             return synthetic_train(model, opts)
-        if opts.model == 'DCGAN':
-            model.train()
+        if opts.model in ('DCGAN', 'CycleGAN'):
+            model.train()           # MNIST idx files / image files under ./data, as in the reference
         else:
-            raise Exception("training %s from files needs the image loaders, which are host-side code outside "
-                            "the accelerated path: call model.train(arrays...) from Python or use --synthetic_iters"
-                            % opts.model)
+            raise Exception("training Text2Image from files needs the flowers caption / image pickles of the "
+                            "reference's data scripts: call model.train(images, captions) from Python or use "
+                            "--synthetic_iters")
     elif opts.phase == 'valid':
         raise Exception("phase 'valid' is not used by the reference's GAN models")
     else:

@@ -63,3 +63,35 @@ def test_undefined_and_out_of_scope_models_raise(tmp_path):
         main(parse(["--model", "nope"] + common))
     with pytest.raises(Exception, match="outside the accelerated"):
         main(parse(["--model", "TextDecoder"] + common))
+
+
+@pytest.mark.gpu
+def test_training_from_image_files_and_sample_grids(tmp_path):
+    """The reference's file pipelines end to end on tiny images: DCGAN (centre crop + resize,
+    dcgan.py:200-221, sample grid :287-317) and CycleGAN (resize / random crop / flip of an A|B pair,
+    misc.py:282-321, translations written like sample_model)."""
+    from PIL import Image
+    from gan_amd.cyclegan import CycleGAN
+    from gan_amd.dcgan import DCGAN
+    rng = np.random.default_rng(0)
+    files = []
+    for i in range(20):
+        p = str(tmp_path / ("img%02d.jpg" % i))
+        Image.fromarray(rng.integers(0, 256, (30, 26, 3)).astype(np.uint8)).save(p)
+        files.append(p)
+    o = parse(("--model DCGAN --dataset celebA --input_height 24 --output_height 16 --batch_size 8 --gf_dim 8 "
+               "--df_dim 8 --z_dim 16 --nEpochs 1").split() + ["--checkpoint_dir", str(tmp_path / "ck"),
+                                                              "--sample_dir", str(tmp_path / "smp")])
+    o.input_width, o.output_width, o.y_dim = 24, 16, None
+    m = DCGAN(None, o, load_data=False)
+    m.train(data_files=files, sample_every=2)
+    grids = sorted((tmp_path / "smp").glob("train_*.png"))
+    assert m.counter == 3 and len(grids) == 1               # 20 files / batch 8 = 2 iterations, one grid
+    assert np.asarray(Image.open(grids[0])).shape == (16 * 3, 16 * 2, 3)     # 8 samples -> 3 x 2 grid
+    o = parse("--model CycleGAN --dataset h2z --batch_size 1 --fine_size 32 --load_size 36 --gf_dim 4 --df_dim 4 "
+              "--max_size 2 --nEpochs 1".split() + ["--checkpoint_dir", str(tmp_path / "ck2"),
+                                                    "--sample_dir", str(tmp_path / "smp2")])
+    c = CycleGAN(None, o)
+    out = c.train(files[:3], files[3:6], sample_every=2)
+    assert all(np.isfinite(float(v)) for v in out.values())
+    assert len(list((tmp_path / "smp2").glob("A_*.jpg"))) == 1 and all(opt.steps_taken == 3 for opt in c.optims.values())

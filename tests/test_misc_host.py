@@ -1,0 +1,73 @@
+"""Host-side image helpers (gan_amd/misc.py) against the behaviour of the reference's models/misc.py."""
+import numpy as np
+import pytest
+from PIL import Image
+
+
+def test_merge_lays_images_out_row_major():
+    from gan_amd.misc import merge
+    imgs = np.stack([np.full((2, 3, 3), i, dtype=np.float64) for i in range(5)])
+    grid = merge(imgs, [2, 3])
+    assert grid.shape == (4, 9, 3)
+    assert grid[0, 0, 0] == 0 and grid[0, 3, 0] == 1 and grid[0, 6, 0] == 2     # first row: images 0, 1, 2
+    assert grid[2, 0, 0] == 3 and grid[2, 3, 0] == 4 and grid[2, 6, 0] == 0     # second row: 3, 4, empty cell
+    gray = merge(imgs[:, :, :, :1], [3, 2])
+    assert gray.shape == (6, 6) and gray[2, 3] == 3
+    with pytest.raises(ValueError):
+        merge(np.zeros((2, 4, 4, 2)), [1, 2])
+    with pytest.raises(ValueError):
+        merge(imgs, [2, 2])
+
+
+def test_bytescale_and_imresize_follow_scipy_misc():
+    from gan_amd.misc import bytescale, imresize
+    u8 = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    assert bytescale(u8) is u8 or np.array_equal(bytescale(u8), u8)
+    f = np.array([[10.0, 20.0], [30.0, 50.0]])
+    np.testing.assert_array_equal(bytescale(f), [[0, 64], [128, 255]])          # stretched to the full range
+    out = imresize(np.full((8, 8, 3), 77, dtype=np.uint8), [4, 6])
+    assert out.shape == (4, 6, 3) and out.dtype == np.uint8 and (out == 77).all()
+
+
+def test_transform_center_crop_and_inverse(tmp_path):
+    from gan_amd.misc import center_crop, get_image, inverse_transform, transform
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 30, 3)).astype(np.uint8)
+    c = center_crop(img, 20, 10, 20, 10)                  # crop only: resize to the same size is the identity
+    np.testing.assert_array_equal(c, img[10:30, 10:20])
+    t = transform(img, 20, 10, 20, 10, crop=True)
+    assert t.min() >= -1.0 and t.max() <= 1.0
+    np.testing.assert_allclose(inverse_transform(t) * 255.0, img[10:30, 10:20], atol=1e-9)
+    path = str(tmp_path / "x.png")
+    Image.fromarray(img).save(path)
+    g = get_image(path, 20, 10, resize_height=8, resize_width=8, crop=True)
+    assert g.shape == (8, 8, 3) and -1.0 <= g.min() and g.max() <= 1.0
+    gg = get_image(path, 20, 10, resize_height=8, resize_width=8, crop=False, grayscale=True)
+    assert gg.shape == (8, 8)
+
+
+def test_save_images_writes_the_grid(tmp_path):
+    from gan_amd.misc import save_images
+    imgs = np.stack([np.full((4, 4, 3), v) for v in (-1.0, 0.0, 1.0, 0.5)])
+    path = save_images(imgs, [2, 2], str(tmp_path / "grid.png"))
+    back = np.asarray(Image.open(path))
+    assert back.shape == (8, 8, 3)
+    assert back[0, 0, 0] == 0 and back[0, 4, 0] == 128 and back[4, 0, 0] == 255 and back[4, 4, 0] == 191
+
+
+def test_cyclegan_pair_loading(tmp_path):
+    from gan_amd.misc import load_data, load_test_data, preprocess_A_and_B
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (50, 60, 3)).astype(np.uint8)
+    b = rng.integers(0, 256, (50, 60)).astype(np.uint8)          # a grey image becomes 3 equal channels
+    pa, pb = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    Image.fromarray(a).save(pa)
+    Image.fromarray(b).save(pb)
+    ab = load_data((pa, pb), load_size=36, fine_size=32, rng=np.random.RandomState(3))
+    assert ab.shape == (32, 32, 6) and ab.min() >= -1.0 and ab.max() <= 1.0
+    np.testing.assert_array_equal(ab[..., 3], ab[..., 4])
+    again = load_data((pa, pb), load_size=36, fine_size=32, rng=np.random.RandomState(3))
+    np.testing.assert_array_equal(ab, again)                      # same seed: same crop and flip
+    ta, tb = preprocess_A_and_B(a, a, load_size=36, fine_size=32, is_test=True)
+    assert ta.shape == (32, 32, 3) and np.array_equal(ta, tb)
+    assert load_test_data(pa, fine_size=16).shape == (16, 16, 3)
