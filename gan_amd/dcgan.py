@@ -118,12 +118,32 @@ class DCGAN(object):
         opts = self.opts
         self.d_group = self.store.pack('d', self.d_vars)
         self.g_group = self.store.pack('g', self.g_vars)
+        self.overlap_exchange = self.world_size > 1 or self.process_group is not None
+        if self.overlap_exchange:
+            # the layers nearest the loss finish their gradients first: their part of each arena is
+            # exchanged while the backward pass of the remaining layers runs (see ops.backward)
+            self.d_group.split_early('discriminator/' + ('d_h2_lin/Matrix' if self.y_dim else 'd_h3_conv/w'))
+            self.g_group.split_early('generator/g_h2/w')
         if self.world_size > 1:
             self.d_group.broadcast(self.process_group)
             self.g_group.broadcast(self.process_group)
         self.d_optim = AdamOptimizer(opts.lr, beta1=opts.beta1).attach(self.d_group)   # dcgan.py:154-157
         self.g_optim = AdamOptimizer(opts.lr, beta1=opts.beta1).attach(self.g_group)
         self.counter = 1
+
+    _d_bound = ()           # set per update; the networks record their boundary activations here
+    _g_bound = None
+
+    def _note_d_boundary(self, t):
+        if isinstance(self._d_bound, list):
+            self._d_bound.append(t)
+
+    def _staged(self, optim, boundary):
+        """Arguments of ops.backward for an update whose gradient exchange overlaps its backward pass."""
+        if not self.overlap_exchange:
+            return {}
+        ws, pg = self.world_size, self.process_group
+        return dict(boundary=boundary, at_boundary=lambda: optim.all_reduce_early(ws, pg))
 
     # ------------------------------------------------------------------------------------ networks
     def discriminator(self, image, y=None, reuse=False, passes=1, with_prob=True):
@@ -141,6 +161,7 @@ class DCGAN(object):
                 h0 = lrelu(conv2d(image, self.df_dim, name='d_h0_conv'))
                 h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)
                 h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)
+                self._note_d_boundary(h2)           # the layers after it own the early part of the d group
                 h3 = self.d_bn3(conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu', passes=passes)
                 h4 = linear(h3.reshape(bs, -1), 1, 'd_h3_lin')
                 return (_sigmoid_value(h4) if with_prob else None), h4
@@ -151,6 +172,7 @@ class DCGAN(object):
             h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv'), act='lrelu', passes=passes)
             h1 = h1.reshape(bs, -1)
             h1 = concat([h1, y], 1)
+            self._note_d_boundary(h1)
             h2 = self.d_bn2(linear(h1, self.dfc_dim, 'd_h2_lin'), act='lrelu', passes=passes)
             h2 = concat([h2, y], 1)
             h3 = linear(h2, 1, 'd_h3_lin')
@@ -174,6 +196,7 @@ class DCGAN(object):
                 h0 = self.g_bn0(self.h0, train=train, act='relu')
                 self.h1, self.h1_w, self.h1_b = deconv2d(h0, [bs, s_h8, s_w8, self.gf_dim * 4], name='g_h1', with_w=True)
                 h1 = self.g_bn1(self.h1, train=train, act='relu')
+                self._g_bound = h1                  # the layers after it own the early part of the g group
                 h2, self.h2_w, self.h2_b = deconv2d(h1, [bs, s_h4, s_w4, self.gf_dim * 2], name='g_h2', with_w=True)
                 h2 = self.g_bn2(h2, train=train, act='relu')
                 h3, self.h3_w, self.h3_b = deconv2d(h2, [bs, s_h2, s_w2, self.gf_dim * 1], name='g_h3', with_w=True)
@@ -190,6 +213,7 @@ class DCGAN(object):
             h1 = self.g_bn1(linear(h0, self.gf_dim * 2 * s_h4 * s_w4, 'g_h1_lin'), train=train, act='relu')
             h1 = h1.reshape(bs, s_h4, s_w4, self.gf_dim * 2)
             h1 = conv_cond_concat(h1, yb)
+            self._g_bound = h1
             h2 = self.g_bn2(deconv2d(h1, [bs, s_h2, s_w2, self.gf_dim * 2], name='g_h2'), train=train, act='relu')
             h2 = conv_cond_concat(h2, yb)
             return ops.sigmoid(deconv2d(h2, [bs, s_h, s_w, self.c_dim], name='g_h3'))
@@ -211,10 +235,11 @@ class DCGAN(object):
         with V.use_store(self.store):
             self.d_optim.begin()
             self._g_pass = None
+            self._d_bound = []
             if keep_g:
                 with ops.moving_update_log() as log, ops.taping():
                     G_taped = self.generator(z, y)
-                self._g_pass = (G_taped, log, z, y)
+                self._g_pass = (G_taped, log, z, y, self._g_bound)
                 G = G_taped.detach()                           # gradients stop at d_vars
             else:
                 with torch.no_grad():
@@ -231,7 +256,8 @@ class DCGAN(object):
                 _, D_logits_ = self.discriminator(G, y, reuse=True)
                 d_loss_real = ops.sigmoid_cross_entropy_mean(D_logits, 1.0)      # dcgan.py:129-132
                 d_loss_fake = ops.sigmoid_cross_entropy_mean(D_logits_, 0.0)
-            ops.backward([d_loss_real, d_loss_fake])
+            ops.backward([d_loss_real, d_loss_fake], **self._staged(self.d_optim, self._d_bound))
+            self._d_bound = ()
             self.d_optim.finish_grads()
         return d_loss_real.detach(), d_loss_fake.detach()
 
@@ -246,14 +272,17 @@ class DCGAN(object):
         with V.use_store(self.store):
             self.g_optim.begin()
             kept, self._g_pass = getattr(self, '_g_pass', None), None
+            self._d_bound = []
             if reuse_g and kept is not None and kept[2] is z and kept[3] is y:
-                G, log = kept[0], kept[1]
+                G, log, bound = kept[0], kept[1], kept[4]
                 log.replay()
             else:
                 G = self.generator(z, y)
+                bound = self._g_bound
             _, D_logits_ = self.discriminator(G, y, reuse=True, with_prob=False)
             g_loss = ops.sigmoid_cross_entropy_mean(D_logits_, 1.0)          # dcgan.py:133-134
-            ops.backward(g_loss)
+            ops.backward(g_loss, **self._staged(self.g_optim, [bound]))
+            self._d_bound, self._g_bound = (), None
             self.g_optim.finish_grads()
         return g_loss.detach()
 

@@ -57,10 +57,11 @@ def _grad_token(device, var=None):
     (tf.gradients prunes the same sub-graph, e.g. G_B2A(real_B) in cyclegan.py's g_loss_a2b)."""
     if var is not None and not var.wants_grad and not _force_tape[0]:
         return None
-    t = _token.get(device)
+    key = (device, bool(var is not None and var.early))
+    t = _token.get(key)
     if t is None:
         t = torch.zeros(1, device=device, requires_grad=True)
-        _token[device] = t
+        _token[key] = t
     return t
 
 
@@ -624,12 +625,33 @@ def l1_mean(a, b, weight=1.0):
 _ones = {}
 
 
-def backward(losses):
-    """Run the backward pass from one or several loss roots (their weights are already applied)."""
+def backward(losses, boundary=None, at_boundary=None):
+    """Run the backward pass from one or several loss roots (their weights are already applied).
+
+    Staged form (data parallel overlap): `boundary` lists the activations that separate the layers
+    owning the EARLY variables of the group being trained (Group.split_early) from the rest.  The
+    pass first runs every layer that leads to those activations or owns an early variable, then
+    calls at_boundary() -- on the calling thread, so it may cut a graph capture and start the
+    exchange of the finished gradients -- and then continues from the boundary downwards.  Every
+    layer that owns a late variable must lie below the boundary."""
     if torch.is_tensor(losses):
         losses = [losses]
     dev = losses[0].device
     one = _ones.get(dev)
     if one is None:
         one = _ones[dev] = torch.ones(1, dtype=torch.float32, device=dev)
-    torch.autograd.backward(list(losses), [one] * len(losses))
+    roots, seeds = list(losses), [one] * len(losses)
+    if boundary:
+        boundary = list(boundary)
+        for t in boundary:
+            if not t.requires_grad:
+                raise ValueError("backward: a boundary activation does not take part in the backward pass")
+        early_token = _token.get((dev, True))
+        wanted = boundary + ([early_token] if early_token is not None else [])
+        grads = torch.autograd.grad(roots, wanted, seeds, allow_unused=True)[:len(boundary)]
+        if any(g is None for g in grads):
+            raise ValueError("backward: a boundary activation is not reachable from the losses")
+        if at_boundary is not None:
+            at_boundary()
+        roots, seeds = boundary, list(grads)
+    torch.autograd.backward(roots, seeds)

@@ -45,9 +45,39 @@ class AdamOptimizer(object):
             from .graph import SegmentedIteration
             SegmentedIteration.cut(lambda: self._all_reduce_now(process_group))
 
+    def all_reduce_early(self, world_size=1, process_group=None):
+        """At the boundary of a staged backward pass (ops.backward): start summing the finished part
+        of the gradient arena over the ranks while the rest of the pass still runs.  The exchange
+        goes on the collective library's own stream; all_reduce() later sums the remaining part and
+        joins both.  A cut of a segmented graph capture, like all_reduce."""
+        if (world_size > 1 or process_group is not None) and self.group.early_offset is not None:
+            self.group.finish_early()
+            from .graph import SegmentedIteration
+            SegmentedIteration.cut(lambda: self._all_reduce_early_now(process_group))
+
+    def _all_reduce_early_now(self, process_group):
+        import torch.distributed as dist
+        part = self.group.early_grads()
+        if part.is_cuda and dist.get_backend(process_group) == "gloo":
+            host = part.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+            part.copy_(host)
+            self._early = True
+        else:
+            self._early = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+
     def _all_reduce_now(self, process_group):
         import torch.distributed as dist
-        grads = self.group.grads
+        early, self._early = getattr(self, '_early', None), None
+        grads = self.group.grads if early is None else self.group.late_grads()
+        try:
+            self._sum(grads, process_group)
+        finally:
+            if early is not None and early is not True:
+                early.wait()            # the current stream waits for the early part's exchange
+
+    def _sum(self, grads, process_group):
+        import torch.distributed as dist
         if grads.is_cuda and dist.get_backend(process_group) == "gloo":
             # gloo (CPU rigs and rehearsals with several ranks on one GPU) moves host memory:
             # stage the arena through the host explicitly instead of relying on gloo's own

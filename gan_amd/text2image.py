@@ -101,6 +101,12 @@ class Text2Image(object):
         self.g_vars = [var for var in t_vars if 'g_' in var.name]
         self.d_group = self.store.pack('d', self.d_vars)
         self.g_group = self.store.pack('g', self.g_vars)
+        self.overlap_exchange = self.world_size > 1 or self.process_group is not None
+        if self.overlap_exchange:
+            # gradients of the layers nearest the loss are exchanged while the backward pass of the
+            # remaining layers runs (ops.backward, DCGAN.build_model)
+            self.d_group.split_early('discriminator/d_h3_conv/w')
+            self.g_group.split_early('generator/g_h2/w')
         if self.world_size > 1:
             self.d_group.broadcast(self.process_group)
             self.g_group.broadcast(self.process_group)
@@ -129,6 +135,7 @@ class Text2Image(object):
 
             h1 = ops.deconv2d(h0, [bs, s8, s8, self.gf_dim * 4], name='g_h1')
             h1 = self.g_bn1(h1, train=train, act='relu')
+            self._g_bound = h1                  # the layers after it own the early part of the g group
 
             h2 = ops.deconv2d(h1, [bs, s4, s4, self.gf_dim * 2], name='g_h2')
             h2 = self.g_bn2(h2, train=train, act='relu')
@@ -153,6 +160,8 @@ class Text2Image(object):
             h0 = ops.lrelu(ops.conv2d(image, self.df_dim, name='d_h0_conv'))                                       # 32
             h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)         # 16
             h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)         # 8
+            if isinstance(self._d_bound, list):
+                self._d_bound.append(h2)        # the layers after it own the early part of the d group
             h3 = self.d_bn3(ops.conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu', passes=passes)         # 4
 
             # ADD TEXT EMBEDDING TO THE NETWORK: expand_dims x2 + tile [1,4,4,1] + concat on channels
@@ -169,6 +178,16 @@ class Text2Image(object):
             return prob, h4
 
     # ---------------------------------------------------------------------------------- updates
+    _d_bound = ()           # set per update; the networks record their boundary activations here
+    _g_bound = None
+
+    def _staged(self, optim, boundary):
+        """Arguments of ops.backward for an update whose gradient exchange overlaps its backward pass."""
+        if not self.overlap_exchange:
+            return {}
+        ws, pg = self.world_size, self.process_group
+        return dict(boundary=boundary, at_boundary=lambda: optim.all_reduce_early(ws, pg))
+
     def d_grads(self, real_image, wrong_image, real_caption, z, keep_g=False):
         """d_loss = d_loss1 + d_loss2 + d_loss3 (text2image.py:88-92) and its gradient w.r.t. d_vars.
         The three discriminator applications (real, wrong, fake image with the same captions) run
@@ -177,10 +196,11 @@ class Text2Image(object):
         with V.use_store(self.store):
             self.d_optim.begin()
             self._g_pass = None
+            self._d_bound = []
             if keep_g:
                 with ops.moving_update_log() as log, ops.taping():
                     taped = self.generator(z, real_caption)
-                self._g_pass = (taped, log, z, real_caption)
+                self._g_pass = (taped, log, z, real_caption, self._g_bound)
                 fake_image = taped.detach()
             else:
                 with torch.no_grad():
@@ -197,7 +217,8 @@ class Text2Image(object):
                 d_loss1 = ops.sigmoid_cross_entropy_mean(real_logits, 1.0)
                 d_loss2 = ops.sigmoid_cross_entropy_mean(wrong_logits, 0.0)
                 d_loss3 = ops.sigmoid_cross_entropy_mean(fake_logits, 0.0)
-            ops.backward([d_loss1, d_loss2, d_loss3])
+            ops.backward([d_loss1, d_loss2, d_loss3], **self._staged(self.d_optim, self._d_bound))
+            self._d_bound = ()
             self.d_optim.finish_grads()
         return d_loss1.detach(), d_loss2.detach(), d_loss3.detach(), fake_image
 
@@ -209,13 +230,15 @@ class Text2Image(object):
             self.g_optim.begin()
             kept, self._g_pass = getattr(self, '_g_pass', None), None
             if reuse_g and kept is not None and kept[2] is z and kept[3] is real_caption:
-                fake_image = kept[0]
+                fake_image, bound = kept[0], kept[4]
                 kept[1].replay()
             else:
                 fake_image = self.generator(z, real_caption)
+                bound = self._g_bound
             _, fake_logits = self.discriminator(fake_image, real_caption, reuse=True, with_prob=False)
             g_loss = ops.sigmoid_cross_entropy_mean(fake_logits, 1.0)
-            ops.backward(g_loss)
+            ops.backward(g_loss, **self._staged(self.g_optim, [bound]))
+            self._g_bound = None
             self.g_optim.finish_grads()
         return g_loss.detach(), fake_image.detach()
 

@@ -31,6 +31,7 @@ class Variable(object):
         self.wants_grad = False     # set per update by the optimiser that owns the variable
         self.grad_fresh = True      # first gradient write of an update overwrites, later ones accumulate
         self.group = None
+        self.early = False          # gradient complete at the backward pass's boundary (Group.split_early)
 
     @property
     def shape(self):
@@ -71,6 +72,36 @@ class Group(object):
             var.grad = self.grads[off:off + n].view(var.data.shape)
             var.group = self
         self.offsets = offs
+        self.early_offset = None
+
+    def split_early(self, first_name):
+        """Data parallel overlap: the variables from `first_name` to the end of the arena (the layers
+        nearest the loss, whose gradients the backward pass finishes first) form the EARLY part, which
+        is exchanged while the backward pass of the remaining layers still runs.  Must be called
+        before the first taped forward pass."""
+        names = [v.name for v in self.variables]
+        if first_name not in names:
+            raise KeyError("group %s has no variable %s" % (self.name, first_name))
+        k = names.index(first_name)
+        for i, v in enumerate(self.variables):
+            v.early = i >= k
+        self.early_offset = self.offsets[k]
+        return self
+
+    def early_grads(self):
+        return self.grads[self.early_offset:]
+
+    def late_grads(self):
+        return self.grads[:self.early_offset]
+
+    def finish_early(self):
+        """At the boundary of a staged backward pass: early variables no gradient reached are
+        zero-filled now, before their part of the arena is exchanged."""
+        from . import _lib
+        for v in self.variables:
+            if v.early and v.grad_fresh:
+                _lib.check(_lib.lib.gan_fill(_lib.ptr(v.grad), v.grad.numel(), 0.0, _lib.stream()))
+                v.grad_fresh = False
 
     def broadcast(self, process_group=None, src=0):
         """Data parallel start-up: every rank takes rank `src`'s values (one collective per group)."""

@@ -50,7 +50,21 @@ def run_cpu(out, rank, world):
     for n, g in local.items():
         res["local/" + n] = g
     for v in grp.variables:
-        res["reduced/" + v.name] = v.grad.numpy()
+        res["reduced/" + v.name] = v.grad.numpy().copy()
+    # the same exchange in two parts: the tail of the arena (from d_bn1/beta on) first, the rest later
+    grp.split_early('discriminator/d_bn1/beta')
+    for v in grp.variables:
+        v.grad.copy_(torch.from_numpy(local[v.name]))
+        v.grad_fresh = False
+    opt.all_reduce_early(world, None)
+    if opt._early is not True:
+        opt._early.wait()                   # the first part is exchanged asynchronously: look at it once it is done
+    res["early_flags"] = np.array([int(v.early) for v in grp.variables])
+    res["after_early_flat"] = grp.grads.numpy().copy()
+    res["early_offset"] = np.array([grp.early_offset])
+    opt.all_reduce(world, None)
+    for v in grp.variables:
+        res["reduced2/" + v.name] = v.grad.numpy().copy()
     np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
 
 

@@ -76,6 +76,16 @@ def test_gloo_broadcast_and_gradient_allreduce(tmp_path):
         total += float(np.abs(want).sum())
     assert abs(float(np.abs(r0["grads_flat"]).sum()) - total) <= 1e-3 * total
     assert int(r0["numel"][0]) % 64 == 0 and int(r0["moving_in_group"][0]) == 0
+    # the exchange in two parts (early tail of the arena while the backward pass still runs, the rest
+    # at its end) leaves the same sums; after the first part only the tail has been summed
+    assert list(r0["early_flags"]) == [0, 0, 1, 1]
+    off = int(r0["early_offset"][0])
+    local0 = np.concatenate([np.pad(r0["local/" + n].ravel(), (0, -r0["local/" + n].size % 64)) for n in names])
+    np.testing.assert_array_equal(r0["after_early_flat"][:off], local0[:off])
+    np.testing.assert_array_equal(r0["after_early_flat"][off:], r0["grads_flat"][off:])
+    for n in names:
+        np.testing.assert_array_equal(r0["reduced2/" + n], r0["reduced/" + n])
+        np.testing.assert_array_equal(r1["reduced2/" + n], r0["reduced/" + n])
 
 
 def test_adam_receives_the_world_average_scale(monkeypatch):

@@ -226,3 +226,42 @@ def test_shared_generator_pass_equals_run_by_run_schedule(cond):
         else:
             assert torch.equal(v.data, w.data), name
     assert a.g_optim.steps_taken == b.g_optim.steps_taken == 6
+
+
+@pytest.mark.parametrize("cond,stacked", [(False, True), (False, False), (True, True)])
+def test_staged_backward_with_early_exchange_equals_plain_backward(cond, stacked, tmp_path):
+    """With a process group the backward pass stops at the boundary activation, starts the exchange of
+    the early part of the gradient arena and continues: on a one-rank group every trained value must
+    come out bit-identical to the unstaged single-process iteration, eager and as a chain of graphs."""
+    import torch.distributed as dist
+    from gan_amd.dcgan import DCGAN
+    opts = make_opts(y_dim=4, c_dim=1, output_height=12, output_width=12, input_height=12) if cond else make_opts()
+    _, plain, rng = build_pair(opts, seed=21)
+    plain.stack_d_passes = stacked
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rendezvous"), rank=0, world_size=1)
+    try:
+        models = []
+        for _ in range(2):
+            m = DCGAN(None, opts, process_group=dist.group.WORLD, load_data=False)
+            m.stack_d_passes = stacked
+            m.store.load_state_dict(plain.store.state_dict())
+            models.append(m)
+        staged, chained = models
+        assert staged.overlap_exchange and staged.d_group.early_offset > 0 and staged.g_group.early_offset > 0
+        assert [v.early for v in staged.g_group.variables].count(True) >= 4
+        batches = [to_dev(*batch(opts, rng, lo=0.0 if cond else -1.0)) for _ in range(3)]
+        run = chained.iteration_runner(*batches[0])
+        for im, z, y in batches:
+            want = plain.train_iteration(im, z, y)
+            got = staged.train_iteration(im, z, y)
+            rep = run(im, z, y)
+            torch.cuda.synchronize()
+            for k in want:
+                assert float(want[k]) == float(got[k]) == float(rep[k]), k
+        for name, v in plain.store.vars.items():
+            assert torch.equal(v.data, staged.store.vars[name].data), name
+            assert torch.equal(v.data, chained.store.vars[name].data), name
+        from gan_amd.graph import SegmentedIteration
+        assert SegmentedIteration.active is None
+    finally:
+        dist.destroy_process_group()

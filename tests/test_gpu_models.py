@@ -363,3 +363,26 @@ def test_text2image_shared_pass_and_stacked_d_equal_separate_runs():
             continue                           # rounding-noise gradients under Adam
         # Adam moves an element whose gradient is rounding noise by up to lr per update: 6 updates of 2e-4
         torch.testing.assert_close(v.data, w.data, rtol=2e-3, atol=1.5e-3)
+
+
+def test_text2image_staged_backward_with_early_exchange_equals_plain(tmp_path):
+    """Text2Image with a (one-rank) process group: the staged backward pass, whose boundary leaves the
+    text-embedding branch of the discriminator on the early side, trains bit-identical values."""
+    import torch.distributed as dist
+    from gan_amd.text2image import Text2Image
+    _, plain, rng, o = t2i_pair(seed=27)
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rendezvous"), rank=0, world_size=1)
+    try:
+        staged = Text2Image(None, o, process_group=dist.group.WORLD)
+        staged.store.load_state_dict(plain.store.state_dict())
+        early = [v.name for v in staged.d_group.variables if v.early]
+        assert 'discriminator/d_embedding/Matrix' in early and 'discriminator/d_h2_conv/w' not in early
+        for _ in range(2):
+            b = [dev(a) for a in t2i_batch(rng, o)]
+            want, got = plain.train_iteration(*b), staged.train_iteration(*b)
+            for k in ('d_loss1', 'd_loss2', 'd_loss3', 'g_loss_1', 'g_loss_2'):
+                assert float(want[k]) == float(got[k]), k
+        for name, v in plain.store.vars.items():
+            assert torch.equal(v.data, staged.store.vars[name].data), name
+    finally:
+        dist.destroy_process_group()
