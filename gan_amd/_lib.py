@@ -71,6 +71,8 @@ SIGNATURES = {
     "gan_conv_plan_get": (I, [I, GeomP, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
     "gan_conv_plan_clear": (None, []),
     "gan_linear_as_conv_geom": (I, [I, I, I, GeomP]),
+    "gan_set_exact_f32": (None, [I]),
+    "gan_get_exact_f32": (I, []),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -25,7 +25,8 @@ _listeners = []     # callables run after plans changed (workspace size caches)
 
 MODES = (0, 1, 2)
 SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96, 128, 192, 256)
-TILE = ((128, 128), (128, 64), (64, 64), (128, 32))
+TILE = ((128, 128), (128, 64), (64, 64), (128, 32), (128, 128), (128, 64), (64, 64))   # 4..6: split-bf16 MFMA
+FIRST_SPLIT_CFG = 4
 MAX_SLAB_BYTES = 256 << 20
 MIN_GAIN = 0.03      # a candidate must beat the heuristic by this fraction to replace it
 
@@ -64,9 +65,12 @@ def _candidates(mode, g):
     m, n, k, out = _problem(mode, g)
     nkt = (k + 15) // 16
     cands = []
+    split_ok = not lib.gan_get_exact_f32() and g.cs % 4 == 0 and (mode == 1 or g.cb % 4 == 0)
     for cfg, (bm, bn) in enumerate(TILE):
         if bn >= 4 * n and bn > 32:
             continue                                  # tile mostly padding in N
+        if cfg >= FIRST_SPLIT_CFG and not split_ok:
+            continue
         tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn)
         for s in SPLITS:
             if s > 1 and (nkt // s < 2 or s * out * 4 > MAX_SLAB_BYTES):

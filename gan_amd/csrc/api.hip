@@ -13,6 +13,8 @@ int conv_geom_check(const gan_conv_geom* g);
 int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits);
 void plan_get(int mode, const gan_conv_geom& g, int* cfg, int* splits, int* thin);
 void plan_clear();
+void set_exact_f32(int on);
+int get_exact_f32();
 size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what);
@@ -274,7 +276,7 @@ static int plan_mode_check(const char* what, int mode) {
 extern "C" int gan_conv_plan_set(int mode, const gan_conv_geom* g, int cfg, int splits) {
     if (int rc = plan_mode_check("gan_conv_plan_set", mode)) return rc;
     if (int rc = conv_geom_check(g)) return rc;
-    GAN_CHECK_ARG(cfg < 4, "gan_conv_plan_set: tile configuration must be 0..3 (or negative to unpin)");
+    GAN_CHECK_ARG(cfg < 7, "gan_conv_plan_set: tile configuration must be 0..6 (or negative to unpin)");
     GAN_CHECK_ARG(cfg < 0 || (splits >= 1 && splits <= 512), "gan_conv_plan_set: split factor must be in 1..512");
     return plan_set(mode, *g, cfg, splits);
 }
@@ -288,6 +290,9 @@ extern "C" int gan_conv_plan_get(int mode, const gan_conv_geom* g, int* cfg, int
 }
 
 extern "C" void gan_conv_plan_clear(void) { plan_clear(); }
+
+extern "C" void gan_set_exact_f32(int on) { set_exact_f32(on); }
+extern "C" int gan_get_exact_f32(void) { return get_exact_f32(); }
 
 extern "C" int gan_linear_as_conv_geom(int rows, int in_dim, int out_dim, gan_conv_geom* g) {
     if (int rc = linear_check("gan_linear_as_conv_geom", rows, in_dim, out_dim)) return rc;

@@ -506,6 +506,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
 }
 
+#include "igemm_split.h"
+
 // out[i] = (accumulate ? out[i] : 0) + bias[i % c] + sum_s slab[s][i]
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                     const float* __restrict__ bias, long elems, int c, int splits,
@@ -677,14 +679,29 @@ struct TileCfg {
 };
 
 struct Plan {
-    int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
+    int cfg;  // fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32; split-bf16 MFMA 4: 128x128, 5: 128x64, 6: 64x64
     int va, vb;
     int splits, kt_per_split;
     int mt, nt;
     long out_elems;
 };
 
-static const TileCfg kCfg[4] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+static const TileCfg kCfg[7] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}};
+constexpr int kFirstSplitCfg = 4, kNumCfg = 7;
+
+// Process-wide switch: 1 keeps every contraction on the fp32 MFMA (bitwise an fmaf chain); 0 lets
+// layers whose channel counts are multiples of 4 run on the bf16 matrix pipe with fp32 operands
+// split into three bf16 parts (igemm_split.h).  GAN_HIP_EXACT_F32 in the environment sets the default.
+static int g_exact_f32 = -1;
+static bool exact_f32() {
+    if (g_exact_f32 < 0) {
+        const char* e = getenv("GAN_HIP_EXACT_F32");
+        g_exact_f32 = (e && *e && *e != '0') ? 1 : 0;
+    }
+    return g_exact_f32 == 1;
+}
+void set_exact_f32(int on) { g_exact_f32 = on ? 1 : 0; }
+int get_exact_f32() { return exact_f32() ? 1 : 0; }
 
 static int geom_check(const gan_conv_geom& g) {
     GAN_CHECK_ARG(g.n > 0 && g.hb > 0 && g.wb > 0 && g.cb > 0 && g.hs > 0 && g.ws > 0 && g.cs > 0,
@@ -779,6 +796,9 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     if (N <= 32) pl.cfg = 3;
     else if (N <= 64) pl.cfg = (M >= 8192) ? 1 : 2;
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
+    // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4
+    const bool split_ok = pl.va == 4 && pl.vb == 4 && !exact_f32();
+    if (split_ok && pl.cfg < 3) pl.cfg += kFirstSplitCfg;
     int pinned_splits = 0;
     {
         std::lock_guard<std::mutex> lock(g_plan_mu);
@@ -788,7 +808,8 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
             pinned_splits = it->second.second;
         }
     }
-    if (const char* e = getenv("GAN_HIP_FORCE_CFG")) pl.cfg = atoi(e) & 3;
+    if (const char* e = getenv("GAN_HIP_FORCE_CFG")) pl.cfg = atoi(e) % kNumCfg;
+    if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;   // pinned or forced, but not eligible
     const int bm = kCfg[pl.cfg].bm, bn = kCfg[pl.cfg].bn;
     pl.mt = (M + bm - 1) / bm;
     pl.nt = (N + bn - 1) / bn;
@@ -876,7 +897,10 @@ static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         case 0: launch_vec<MODE, 128, 128, 2, 2>(a, pl, grid, s); break;
         case 1: launch_vec<MODE, 128, 64, 2, 2>(a, pl, grid, s); break;
         case 2: launch_vec<MODE, 64, 64, 2, 2>(a, pl, grid, s); break;
-        default: launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break;
+        case 3: launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break;
+        case 4: hipLaunchKernelGGL((igemm_split_kernel<MODE, 128, 128, 2, 2>), grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((igemm_split_kernel<MODE, 128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((igemm_split_kernel<MODE, 64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
     }
 }
 
@@ -967,7 +991,7 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
 int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits) {
     std::lock_guard<std::mutex> lock(g_plan_mu);
     if (cfg < 0) plan_table().erase(plan_key(mode, g));
-    else plan_table()[plan_key(mode, g)] = std::make_pair(cfg & 3, splits);
+    else plan_table()[plan_key(mode, g)] = std::make_pair(cfg % kNumCfg, splits);
     return 0;
 }
 

@@ -1,0 +1,425 @@
+// fp32 contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), gfx950.
+// Included by igemm.hip inside namespace gan, after IgemmArgs / ClassInfo / fdiv.
+//
+// The fp32 MFMA runs at the vector rate (64 FLOP/clk/SIMD); the bf16 MFMA is 16 times faster.
+// An fp32 value x is written EXACTLY as the sum of three bf16 values h + m + l (each holds the next
+// 8 significant bits of x: 24 = 3 x 8), so a product a*b is the sum of nine bf16 x bf16 products,
+// each of which the matrix pipe forms exactly and adds into an fp32 accumulator.  The three
+// smallest ones (m*l, l*m, l*l <= 2^-23 |a*b| together) are dropped, which is below the rounding
+// error of a single fp32 product; the remaining six cost 6/16 of the fp32 MFMA's time.
+//
+// The split happens when a tile is written to LDS: the loaders fetch fp32 exactly like the fp32
+// kernel (same gather arithmetic, same masking), split every value into its three parts with four
+// integer / fp32 vector instructions, and store three bf16 images per operand.  LDS image of one
+// operand and one part: [k / 8][row position][8 consecutive k] (16 bytes per row and 8-deep group),
+// so a fragment of the 32x32x16 MFMA (lane: row l % 32, k = 8 * (l / 32) .. +7) is one 16-byte read
+// from 32 consecutive addresses per half wave.
+//
+// Loader shapes (BK = 16 deep slices, 256 threads):
+//   * operand contiguous along k in memory (A of FPROP / TPROP, B of TPROP): a thread loads one
+//     float4 = 4 consecutive k of one row per pass and writes 8 bytes per part;
+//   * operand contiguous along its rows (B of FPROP, A and B of WGRAD): a thread loads 4 consecutive
+//     k rows x 2 adjacent rows (four float2), transposes in registers and writes 8 bytes per part
+//     and row.  Adjacent lanes hold the two 4-deep halves of one 8-deep group, and the row pair
+//     (2c, 2c+1) is stored at positions (c, ROWS/2 + c), so a wave's stores cover consecutive
+//     addresses; the epilogue undoes that row permutation.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x0, x1 -> packed bf16 pairs (x0 in the low half) of the three parts
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);   // exact: the low 16 significand bits
+    const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);   // exact: at most 8 significant bits left
+    const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);            // (u1 & 0xffff0000) | (u0 >> 16)
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// position in the LDS image -> row of the tile, for an operand filled by the row-pair loader
+template <int ROWS>
+__device__ __forceinline__ int unpermute(int pos) {
+    return 2 * (pos % (ROWS / 2)) + pos / (ROWS / 2);
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
+    static_assert(WM * WN == 4, "four waves per block");
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile sides are multiples of 64");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr bool A_TRANS = (MODE != MODE_WGRAD);  // A source contiguous along k
+    constexpr bool B_TRANS = (MODE == MODE_TPROP);  // B source contiguous along k
+    constexpr int GA = (BM + 8) * 16, GB = (BN + 8) * 16;  // bytes of one 8-deep group of one part
+    constexpr int PA = 2 * GA, PB = 2 * GB;                // one part of a 16-deep slice
+    constexpr int STAGE = 3 * (PA + PB);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int split = blockIdx.z % p.splits;
+    const int ci = blockIdx.z / p.splits;
+    const gan_conv_geom& g = p.g;
+
+    int M, N, K;
+    ClassInfo cl = p.cls[0];
+    if constexpr (MODE == MODE_TPROP) {
+        if (ci == 1) cl = p.cls[1];
+        else if (ci == 2) cl = p.cls[2];
+        else if (ci == 3) cl = p.cls[3];
+        M = cl.M; K = cl.K; N = g.cb;
+    } else {
+        M = p.M; N = p.N; K = p.K;
+    }
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;  // block-uniform
+    const int n0 = blockIdx.y * BN;
+    const int nkt = (K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nkt, kt0 + p.kt_per_split);
+    const int kend = min(K, kt1 * BK);
+
+    // ---------------------------------------------------------------- A loader set-up
+    constexpr int A_PASS = A_TRANS ? BM / 64 : 4;   // k-contiguous: rows per thread; else: k rows per thread
+    constexpr int A_W = A_TRANS ? 4 : 2;
+    const int SH = (MODE == MODE_TPROP) ? g.hs : g.hb;
+    const int SW = (MODE == MODE_TPROP) ? g.ws : g.wb;
+    const int SC = (MODE == MODE_TPROP) ? g.cs : g.cb;
+    const FastDiv dSC = (MODE == MODE_TPROP) ? p.d_cs : p.d_cb;
+    const FastDiv dTW = (MODE == MODE_TPROP) ? cl.d_kwc : p.d_kw;
+    // k-contiguous loader: thread -> (4-deep k group, row)
+    const int t_kq = tid & 3, t_r = tid >> 2;
+    int a_base[A_TRANS ? A_PASS : 1], a_y0[A_TRANS ? A_PASS : 1], a_x0[A_TRANS ? A_PASS : 1];
+    // row-pair loader of A (WGRAD): thread -> (k group a_kq, row pair a_rc); 2 * BM threads take part
+    const bool a_on = A_TRANS || tid < 2 * BM;
+    const int a_rc = (tid >> 1) % (BM / 2);
+    const int a_kq = ((tid / BM) << 1) | (tid & 1);
+    int a_kh = 0, a_kw = 0, a_c = 0;
+    bool a_mvalid = true;
+    if constexpr (A_TRANS) {
+        const int row_w = (MODE == MODE_TPROP) ? cl.wq : g.ws;
+        const int row_hw = (MODE == MODE_TPROP) ? cl.hq * cl.wq : g.hs * g.ws;
+#pragma unroll
+        for (int ps = 0; ps < A_PASS; ++ps) {
+            const int m = m0 + t_r + ps * 64;
+            const bool ok = m < M;
+            const unsigned um = ok ? (unsigned)m : 0u;
+            const int img = um / (unsigned)row_hw;
+            const int rem = um - img * row_hw;
+            const int y = rem / row_w, x = rem - y * row_w;
+            a_base[ps] = ok ? img * SH * SW : -1;
+            if constexpr (MODE == MODE_TPROP) {
+                a_y0[ps] = cl.hq0 + y;
+                a_x0[ps] = cl.wq0 + x;
+            } else {
+                a_y0[ps] = y * g.sh - g.pt;
+                a_x0[ps] = x * g.sw - g.pl;
+            }
+        }
+    } else {
+        const int m = m0 + 2 * a_rc;
+        a_mvalid = a_on && m < M;
+        const unsigned um = a_mvalid ? (unsigned)m : 0u;
+        const int tap = um / (unsigned)g.cb;
+        a_c = um - tap * g.cb;
+        a_kh = tap / g.kw;
+        a_kw = tap - a_kh * g.kw;
+    }
+
+    // ---------------------------------------------------------------- B loader set-up
+    constexpr int B_PASS = B_TRANS ? BN / 64 : 4;
+    constexpr int B_W = B_TRANS ? 4 : 2;
+    // row-pair loader of B: the LAST 2 * BN threads take part (the first ones carry A's when BM is small)
+    constexpr int B_T0 = 256 - (2 * BN < 256 ? 2 * BN : 256);
+    const int bt = tid - B_T0;
+    const bool b_on = B_TRANS || bt >= 0;
+    const int btc = bt >= 0 ? bt : 0;
+    const int b_rc = (btc >> 1) % (BN / 2);
+    const int b_kq = ((btc / BN) << 1) | (btc & 1);
+
+    float a_reg[A_PASS][A_W], b_reg[B_PASS][B_W];
+    bool a_ok[A_PASS], b_ok[B_PASS];
+
+    auto load_a = [&](int kt) {
+        if constexpr (A_TRANS) {
+            const int k = kt * BK + t_kq * 4;
+            const bool kv = k < kend;
+            const unsigned uk = kv ? (unsigned)k : 0u;
+            const int tapc = fdiv(uk, dSC);
+            const int cc = uk - tapc * SC;
+            const int ta = fdiv(tapc, dTW);
+            const int tb = tapc - ta * (int)dTW.d;
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
+                const int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                const bool ok = kv && a_base[ps] >= 0 && (unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW;
+                const long off = ((long)(a_base[ps] + iy * SW + ix)) * SC + cc;
+                load_vec<4>(a_reg[ps], p.a, off, ok);
+                a_ok[ps] = ok;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kt * BK + a_kq * 4 + j;
+                const bool kv = (k < kend) && a_mvalid;
+                const unsigned uk = kv ? (unsigned)k : 0u;
+                const int img = fdiv(uk, p.d_hsws);
+                const int rem = uk - img * (int)p.d_hsws.d;
+                const int oy = fdiv(rem, p.d_ws);
+                const int ox = rem - oy * g.ws;
+                const int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
+                const bool ok = kv && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
+                const long off = ((long)((img * g.hb + iy) * g.wb + ix)) * g.cb + a_c;
+                const float2 v = *reinterpret_cast<const float2*>(p.a + (ok ? off : 0L));
+                a_reg[j][0] = v.x; a_reg[j][1] = v.y;
+                a_ok[j] = ok;
+            }
+        }
+    };
+
+    auto load_b = [&](int kt) {
+        if constexpr (B_TRANS) {
+            const int k = kt * BK + t_kq * 4;
+            const bool kv = k < kend;
+            const unsigned uk = kv ? (unsigned)k : 0u;
+            const int tapc = fdiv(uk, p.d_cs);
+            const int cc = uk - tapc * g.cs;
+            const int ta = fdiv(tapc, cl.d_kwc);
+            const int tb = tapc - ta * cl.kwc;
+            const int wtap = (cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb);
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const int n = n0 + t_r + ps * 64;
+                const bool ok = kv && (n < N);
+                const long off = ((long)(wtap * g.cb + n)) * g.cs + cc;
+                load_vec<4>(b_reg[ps], p.b, off, ok);
+                b_ok[ps] = ok;
+            }
+        } else {
+            const int n = n0 + 2 * b_rc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kt * BK + b_kq * 4 + j;
+                const bool ok = b_on && (k < kend) && (n < N);
+                const long off = (long)k * N + n;
+                const float2 v = *reinterpret_cast<const float2*>(p.b + (ok ? off : 0L));
+                b_reg[j][0] = v.x; b_reg[j][1] = v.y;
+                b_ok[j] = ok;
+            }
+        }
+    };
+
+    // 4 consecutive k of one row -> 8 bytes of each part at (8-deep group kq >> 1, half kq & 1)
+    auto put = [&](unsigned char* img, int part_bytes, int group_bytes, int kq, int pos, float x0, float x1, float x2,
+                   float x3) {
+        unsigned h01, m01, l01, h23, m23, l23;
+        split3(x0, x1, h01, m01, l01);
+        split3(x2, x3, h23, m23, l23);
+        unsigned char* q = img + (kq >> 1) * group_bytes + pos * 16 + (kq & 1) * 8;
+        *reinterpret_cast<uint2*>(q) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(q + part_bytes) = make_uint2(m01, m23);
+        *reinterpret_cast<uint2*>(q + 2 * part_bytes) = make_uint2(l01, l23);
+    };
+
+    auto store_a = [&](int buf) {
+        unsigned char* As = smem_raw + buf * STAGE;
+        if constexpr (A_TRANS) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const bool ok = a_ok[ps];
+                put(As, PA, GA, t_kq, t_r + ps * 64, ok ? a_reg[ps][0] : 0.f, ok ? a_reg[ps][1] : 0.f,
+                    ok ? a_reg[ps][2] : 0.f, ok ? a_reg[ps][3] : 0.f);
+            }
+        } else {
+            if (a_on) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    put(As, PA, GA, a_kq, e * (BM / 2) + a_rc, a_ok[0] ? a_reg[0][e] : 0.f, a_ok[1] ? a_reg[1][e] : 0.f,
+                        a_ok[2] ? a_reg[2][e] : 0.f, a_ok[3] ? a_reg[3][e] : 0.f);
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+        unsigned char* Bs = smem_raw + buf * STAGE + 3 * PA;
+        if constexpr (B_TRANS) {
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const bool ok = b_ok[ps];
+                put(Bs, PB, GB, t_kq, t_r + ps * 64, ok ? b_reg[ps][0] : 0.f, ok ? b_reg[ps][1] : 0.f,
+                    ok ? b_reg[ps][2] : 0.f, ok ? b_reg[ps][3] : 0.f);
+            }
+        } else {
+            if (b_on) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    put(Bs, PB, GB, b_kq, e * (BN / 2) + b_rc, b_ok[0] ? b_reg[0][e] : 0.f, b_ok[1] ? b_reg[1][e] : 0.f,
+                        b_ok[2] ? b_reg[2][e] : 0.f, b_ok[3] ? b_reg[3][e] : 0.f);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kh2 = lane >> 5;
+    const int frag_a = kh2 * GA + (wm * (BM / WM) + (lane & 31)) * 16;
+    const int frag_b = kh2 * GB + (wn * (BN / WN) + (lane & 31)) * 16;
+
+    if (kt0 < kt1) {
+        // Software pipeline, one barrier per slice (as in igemm_kernel): slice kt is multiplied out of
+        // LDS buffer `buf` while slice kt+1 (in registers) is split and written to the other buffer
+        // and the global loads of slice kt+2 are issued.
+        load_a(kt0);
+        load_b(kt0);
+        store_a(0);
+        store_b(0);
+        load_a(kt0 + 1);
+        load_b(kt0 + 1);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const unsigned char* As = smem_raw + buf * STAGE;
+            const unsigned char* Bs = As + 3 * PA;
+            bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(As + s * PA + frag_a + i * 32 * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(Bs + s * PB + frag_b + j * 32 * 16);
+            }
+            store_a(buf ^ 1);
+            store_b(buf ^ 1);
+            load_a(kt + 2);
+            load_b(kt + 2);
+            // six of the nine part products, smallest first: l*h, h*l, m*m, m*h, h*m, h*h
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue (as igemm_kernel, plus the
+    // row / column permutation of operands filled by the row-pair loader)
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    __shared__ int rowoff[BM];
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < M) {
+            if constexpr (MODE == MODE_TPROP) {
+                const int hw = cl.hq * cl.wq;
+                const int img = m / hw;
+                const int rem = m - img * hw;
+                const int yq = rem / cl.wq, xq = rem - yq * cl.wq;
+                const int y = g.sh * (cl.hq0 + yq) + cl.ph - g.pt;
+                const int x = g.sw * (cl.wq0 + xq) + cl.pw - g.pl;
+                off = ((img * g.hb + y) * g.wb + x) * g.cb;
+            } else {
+                off = m * N;
+            }
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+
+    float* dst = p.out + (p.splits > 1 ? (long)split * p.slab_elems : 0L);
+    const bool direct = p.splits == 1;
+    const bool accum = direct && p.accumulate;
+
+    int tcol[TN];  // tile column of this lane's accumulator column j
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pos = wn * (BN / WN) + j * 32 + (lane & 31);
+        tcol[j] = B_TRANS ? pos : unpermute<BN>(pos);
+    }
+
+    if (p.vec_epilogue) {
+        constexpr int R = ((2 * STAGE / 4) / BN / 32) * 32 < BM ? ((2 * STAGE / 4) / BN / 32) * 32 : BM;
+        static_assert(R >= 32, "LDS staging must hold a 32-row group of the tile");
+        constexpr int F4_ROW = BN / 4;
+        const bool has_bias = direct && p.bias != nullptr;
+        // staging rows are tile ROWS (after the permutation), so a pass covers rows [r0, r0 + R)
+#pragma unroll
+        for (int r0 = 0; r0 < BM; r0 += R) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pos = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+                    const int row = A_TRANS ? pos : unpermute<BM>(pos);
+                    if (row >= r0 && row < r0 + R) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) smem[(row - r0) * BN + tcol[j]] = acc[i][j][r];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f = tid; f < R * F4_ROW; f += 256) {
+                const int row = f / F4_ROW, c4 = f - row * F4_ROW;
+                const int off = (r0 + row < BM) ? rowoff[r0 + row] : -1;
+                const int col = n0 + c4 * 4;
+                if (off >= 0 && col < N) {
+                    float4 v = *reinterpret_cast<const float4*>(&smem[row * BN + c4 * 4]);
+                    if (has_bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    float4* o = reinterpret_cast<float4*>(dst + off + col);
+                    if (accum) {
+                        const float4 old = *o;
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    }
+                    *o = v;
+                }
+            }
+            if (r0 + R < BM) __syncthreads();
+        }
+        return;
+    }
+
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        bias_v[j] = (direct && p.bias != nullptr && n0 + tcol[j] < N) ? p.bias[n0 + tcol[j]] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pos = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+            const int off = rowoff[A_TRANS ? pos : unpermute<BM>(pos)];
+            if (off < 0) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + tcol[j];
+                if (col < N) {
+                    float v = acc[i][j][r] + bias_v[j];
+                    if (accum) v += dst[off + col];
+                    dst[off + col] = v;
+                }
+            }
+        }
+    }
+}

@@ -179,7 +179,9 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
  *   mode 0: conv2d_fwd, deconv2d_dgrad, linear_fwd
  *   mode 1: conv2d_dgrad, deconv2d_fwd, linear_dgrad
  *   mode 2: conv2d_wgrad, deconv2d_wgrad, linear_wgrad
- * gan_conv_plan_set pins the tile configuration (0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32) and
+ * gan_conv_plan_set pins the tile configuration (fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64,
+ * 3: 128x32; bf16 MFMA on fp32 operands split into three bf16 parts 4: 128x128, 5: 128x64,
+ * 6: 64x64, which need channel counts that are multiples of 4 and fall back to 0..2 otherwise) and
  * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
  * gan_conv_plan_get reports the plan in effect (`thin` = 1 when mode 1 takes the vector-ALU path
  * for outputs of <= 4 channels, which has no plan).  Changing a plan changes the workspace size
@@ -189,6 +191,17 @@ int gan_conv_plan_set(int mode, const gan_conv_geom* g, int cfg, int splits);
 int gan_conv_plan_get(int mode, const gan_conv_geom* g, int* cfg, int* splits, int* thin);
 void gan_conv_plan_clear(void);
 int gan_linear_as_conv_geom(int rows, int in_dim, int out_dim, gan_conv_geom* g);
+
+/* ---- arithmetic of the contractions (no counterpart in the reference: tf.nn.conv2d computes in
+ * fp32 on whatever device it runs) --------------------------------------------------------
+ * By default a contraction whose channel counts are multiples of 4 runs on the bf16 matrix pipe:
+ * every fp32 operand value is split exactly into three bf16 parts (8 + 8 + 8 significand bits) and
+ * six of the nine part products are accumulated in fp32; the three dropped ones are together below
+ * 2^-23 of the product, i.e. below the rounding of one fp32 multiplication.  gan_set_exact_f32(1)
+ * keeps every contraction on the fp32 MFMA instead (bitwise an fmaf chain per output element);
+ * the environment variable GAN_HIP_EXACT_F32=1 makes that the default of the process. */
+void gan_set_exact_f32(int on);
+int gan_get_exact_f32(void);
 
 /* ---- utilities ------------------------------------------------------------------------- */
 int gan_fill(float* x, long n, float value, gan_stream_t stream);
