@@ -67,7 +67,20 @@ def test_plan_pinning_is_host_side_bookkeeping():
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     assert get(0) == heur
     assert L.lib.gan_conv_plan_set(3, gp, 0, 1) != 0 and b"mode" in L.lib.gan_last_error()
-    assert L.lib.gan_conv_plan_set(0, gp, 4, 1) != 0
+    assert L.lib.gan_conv_plan_set(0, gp, 7, 1) != 0
+    # configurations 4..6 are the split-bf16 kernels: the heuristic takes them for channel counts that are
+    # multiples of 4, a pin is honoured, and the exact-fp32 switch (or an odd channel count) maps them back
+    assert heur[0] >= 4 and L.lib.gan_get_exact_f32() == 0
+    L.check(L.lib.gan_conv_plan_set(0, gp, 5, 2))
+    assert get(0)[:2] == (5, 2)
+    L.lib.gan_set_exact_f32(1)
+    assert get(0)[:2] == (1, 2) and L.lib.gan_get_exact_f32() == 1
+    L.lib.gan_set_exact_f32(0)
+    L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
+    godd = L.conv_geom(8, 16, 16, 6, 8, 8, 10, 5, 5, 2, 2, 1, 1)
+    L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 6, 1))
+    L.check(L.lib.gan_conv_plan_get(0, ctypes.byref(godd), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+    assert c.value == 2
     # thin outputs of the transposed contraction have no plan
     g3 = L.conv_geom(64, 64, 64, 3, 32, 32, 64, 5, 5, 2, 2, 1, 1)
     L.check(L.lib.gan_conv_plan_get(1, ctypes.byref(g3), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))

@@ -99,11 +99,30 @@ def test_conv2d_small(L, case):
     _conv_case(L, case)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_conv2d_every_tile_config_and_split(L, cfg, splits):
     _conv_case(L, (2, 12, 12, 8, 40, 5, 2, 'SAME'), cfg, splits)
-    _conv_case(L, (2, 9, 9, 5, 7, 3, 1, 'SAME'), cfg, splits)
+    _conv_case(L, (2, 9, 9, 5, 7, 3, 1, 'SAME'), cfg, splits)      # odd channels: 4..6 fall back to 0..2
+
+
+# channel counts that are multiples of 4 (the split-bf16 kernels' condition) with ragged tiles:
+# rows, columns and depth that are not multiples of the tile sides / of the 16-deep slice
+SPLIT_CONVS = [
+    (3, 14, 14, 20, 76, 5, 2, 'SAME'),      # N = 76: one full and one ragged 64-wide column tile
+    (1, 17, 11, 12, 136, 3, 1, 'SAME'),     # K = 108 (not a multiple of 16), N = 136, M = 187
+    (2, 9, 13, 8, 12, 5, 2, 'SAME'),        # N = 12: every tile mostly padding
+    (5, 4, 4, 24, 16, 1, 1, 'SAME'),        # 1x1: K = 24
+    (1, 10, 10, 8, 8, 3, 1, 'VALID'),
+    (2, 16, 16, 12, 4, 5, 1, 'SAME'),       # transposed contraction with 12 output channels
+]
+
+
+@pytest.mark.parametrize("cfg", [4, 5, 6])
+@pytest.mark.parametrize("case", SPLIT_CONVS)
+def test_conv2d_split_bf16_kernels_on_ragged_shapes(L, cfg, case):
+    _conv_case(L, case, cfg, 1)
+    _conv_case(L, case, cfg, 2)
 
 
 @pytest.mark.parametrize("case", DCGAN_CONVS)
@@ -166,7 +185,7 @@ def test_deconv2d_small(L, case):
     _deconv_case(L, case)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("splits", [1, 2])
 def test_deconv2d_every_tile_config_and_split(L, cfg, splits):
     _deconv_case(L, (2, 6, 6, 8, 36, 5, 2, 12, 12), cfg, splits)
@@ -470,3 +489,42 @@ def test_autotuned_plans_keep_parity(L):
     finally:
         autotune.reset()
     assert autotune.report() == {}
+
+
+def test_split_bf16_arithmetic_is_as_accurate_as_the_fp32_mfma(L):
+    """The default contraction arithmetic (fp32 operands split exactly into three bf16 parts, six
+    part products on the bf16 matrix pipe, fp32 accumulation) against the float64 oracle, next to
+    the exact fp32 MFMA (gan_set_exact_f32): both far inside the 1e-4 bar and within a small factor of
+    each other -- the difference is summation order, not operand precision."""
+    from gpu_util import dev, geom_for, host
+    n, h, w, cb, cs, k, s, padding = DCGAN_CONVS[2]
+    x = RNG.standard_normal((n, h, w, cb)).astype(np.float32)
+    wt = (RNG.standard_normal((k, k, cb, cs)) * 0.05).astype(np.float32)
+    g = geom_for(n, h, w, cb, cs, k, s, padding)
+    y_ref = T.conv2d_forward(x.astype(np.float64), wt.astype(np.float64), s, s, padding)
+    dy = RNG.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = T.conv2d_backward_input(dy.astype(np.float64), wt.astype(np.float64), x.shape, s, s, padding)
+    dw_ref = T.conv2d_backward_filter(x.astype(np.float64), dy.astype(np.float64), k, k, s, s, padding)
+    xd, wd, dyd = dev(x), dev(wt), dev(dy)
+    y, dx, dw = torch.empty(y_ref.shape, device='cuda'), torch.empty(x.shape, device='cuda'), torch.empty(wt.shape, device='cuda')
+    gp = ctypes.byref(g)
+    c, sp, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    errs = {}
+    try:
+        for exact in (1, 0):
+            L.lib.gan_set_exact_f32(exact)
+            wp, wn = _ws(L, g)
+            st = L.stream()
+            L.check(L.lib.gan_conv_plan_get(0, gp, ctypes.byref(c), ctypes.byref(sp), ctypes.byref(thin)))
+            assert (c.value >= 4) == (exact == 0)
+            L.check(L.lib.gan_conv2d_fwd(gp, L.ptr(xd), L.ptr(wd), None, L.ptr(y), wp, wn, st))
+            L.check(L.lib.gan_conv2d_dgrad(gp, L.ptr(dyd), L.ptr(wd), L.ptr(dx), wp, wn, st))
+            L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(xd), L.ptr(dyd), L.ptr(dw), None, 0, wp, wn, st))
+            torch.cuda.synchronize()
+            errs[exact] = [float(np.abs(host(t) - r).max() / np.abs(r).max())
+                           for t, r in ((y, y_ref), (dx, dx_ref), (dw, dw_ref))]
+    finally:
+        L.lib.gan_set_exact_f32(0)
+    for e_exact, e_split in zip(errs[1], errs[0]):
+        assert e_exact < 5e-6 and e_split < 5e-6, errs
+        assert e_split < 4 * e_exact + 2e-7, errs
