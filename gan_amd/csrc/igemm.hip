@@ -74,6 +74,7 @@ struct IgemmArgs {
     long slab_elems;
     int accumulate;
     int vec_epilogue;  // rows of the output are 16-byte aligned and N % 4 == 0: float4 stores
+    unsigned a_bytes, b_bytes;  // sizes of the two operand tensors (buffer range checks of the split kernel)
     int ncls;
     FastDiv d_cb, d_cs, d_kw, d_hsws, d_ws;
     ClassInfo cls[kMaxClasses];
@@ -797,7 +798,7 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     else if (N <= 64) pl.cfg = (M >= 8192) ? 1 : 2;
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
     // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4
-    const bool split_ok = pl.va == 4 && pl.vb == 4 && !exact_f32();
+    const bool split_ok = pl.va == 4 && pl.vb == 4 && a.a_bytes != 0 && a.b_bytes != 0 && !exact_f32();
     if (split_ok && pl.cfg < 3) pl.cfg += kFirstSplitCfg;
     int pinned_splits = 0;
     {
@@ -978,13 +979,22 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.d_hsws = make_fastdiv((unsigned)(g.hs * g.ws));
     r.d_ws = make_fastdiv((unsigned)g.ws);
     for (int i = 0; i < kMaxClasses; ++i) r.cls[i] = ClassInfo{0, 0, 1, 1, 0, 0, 0, 0, 0, 0, make_fastdiv(1)};
+    const uint64_t big_b = 4ull * g.n * g.hb * g.wb * g.cb, small_b = 4ull * g.n * g.hs * g.ws * g.cs;
+    const uint64_t filt_b = 4ull * g.kh * g.kw * g.cb * g.cs;
+    const uint64_t cap = 0xffffffe0ull;  // operands beyond 4 GB keep the fp32 kernel (make_plan)
+    uint64_t ab, bb;
     if (mode == MODE_FPROP) {
         r.M = g.n * g.hs * g.ws; r.N = g.cs; r.K = g.kh * g.kw * g.cb;
+        ab = big_b; bb = filt_b;
     } else if (mode == MODE_WGRAD) {
         r.M = g.kh * g.kw * g.cb; r.N = g.cs; r.K = g.n * g.hs * g.ws;
+        ab = big_b; bb = small_b;
     } else {
         r.M = 0; r.N = g.cb; r.K = 0;
+        ab = small_b; bb = filt_b;
     }
+    r.a_bytes = (unsigned)(ab < cap ? ab : 0);
+    r.b_bytes = (unsigned)(bb < cap ? bb : 0);
     return r;
 }
 

@@ -25,6 +25,13 @@
 //     addresses; the epilogue undoes that row permutation.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// The gathers go through buffer descriptors: a masked-off lane (padding tap, row beyond the problem,
+// tail of K) presents an offset beyond the buffer and the hardware range check returns zeros, so
+// neither the address nor the loaded values need a select per element.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOutOfRange = 0xfffffff0u;
+
 // x0, x1 -> packed bf16 pairs (x0 in the low half) of the three parts
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
@@ -54,6 +61,8 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     constexpr int GA = (BM + 8) * 16, GB = (BN + 8) * 16;  // bytes of one 8-deep group of one part
     constexpr int PA = 2 * GA, PB = 2 * GB;                // one part of a 16-deep slice
     constexpr int STAGE = 3 * (PA + PB);
+    // vector instructions of one slice (split, address arithmetic) per MFMA of that slice
+    constexpr int kValuPerMfma = (TM * TN >= 4) ? 7 : (TM * TN == 2 ? 11 : 20);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[2 * STAGE];
 
     const int tid = threadIdx.x;
@@ -140,10 +149,23 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     const int b_rc = (btc >> 1) % (BN / 2);
     const int b_kq = ((btc / BN) << 1) | (btc & 1);
 
-    float a_reg[A_PASS][A_W], b_reg[B_PASS][B_W];
-    bool a_ok[A_PASS], b_ok[B_PASS];
+    typedef float AReg[A_PASS][A_W];
+    typedef float BReg[B_PASS][B_W];
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
+    auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off, float (&dst)[4]) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+        dst[0] = __uint_as_float(v[0]); dst[1] = __uint_as_float(v[1]);
+        dst[2] = __uint_as_float(v[2]); dst[3] = __uint_as_float(v[3]);
+    };
+    auto ld2 = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off, float (&dst)[2]) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+        dst[0] = __uint_as_float(v[0]); dst[1] = __uint_as_float(v[1]);
+    };
 
-    auto load_a = [&](int kt) {
+    auto load_a = [&](int kt, AReg& a_reg) {
         if constexpr (A_TRANS) {
             const int k = kt * BK + t_kq * 4;
             const bool kv = k < kend;
@@ -156,32 +178,29 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
             for (int ps = 0; ps < A_PASS; ++ps) {
                 const int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
                 const int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
-                const bool ok = kv && a_base[ps] >= 0 && (unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW;
-                const long off = ((long)(a_base[ps] + iy * SW + ix)) * SC + cc;
-                load_vec<4>(a_reg[ps], p.a, off, ok);
-                a_ok[ps] = ok;
+                const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
+                const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
+                ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kt * BK + a_kq * 4 + j;
-                const bool kv = (k < kend) && a_mvalid;
+                const bool kv = (k < kend) & a_mvalid;
                 const unsigned uk = kv ? (unsigned)k : 0u;
                 const int img = fdiv(uk, p.d_hsws);
                 const int rem = uk - img * (int)p.d_hsws.d;
                 const int oy = fdiv(rem, p.d_ws);
                 const int ox = rem - oy * g.ws;
                 const int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
-                const bool ok = kv && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
-                const long off = ((long)((img * g.hb + iy) * g.wb + ix)) * g.cb + a_c;
-                const float2 v = *reinterpret_cast<const float2*>(p.a + (ok ? off : 0L));
-                a_reg[j][0] = v.x; a_reg[j][1] = v.y;
-                a_ok[j] = ok;
+                const bool ok = kv & ((unsigned)iy < (unsigned)g.hb) & ((unsigned)ix < (unsigned)g.wb);
+                const unsigned off = (unsigned)(((img * g.hb + iy) * g.wb + ix) * g.cb + a_c) * 4u;
+                ld2(rsrc_a, ok ? off : kOutOfRange, a_reg[j]);
             }
         }
     };
 
-    auto load_b = [&](int kt) {
+    auto load_b = [&](int kt, BReg& b_reg) {
         if constexpr (B_TRANS) {
             const int k = kt * BK + t_kq * 4;
             const bool kv = k < kend;
@@ -194,21 +213,18 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const int n = n0 + t_r + ps * 64;
-                const bool ok = kv && (n < N);
-                const long off = ((long)(wtap * g.cb + n)) * g.cs + cc;
-                load_vec<4>(b_reg[ps], p.b, off, ok);
-                b_ok[ps] = ok;
+                const bool ok = kv & (n < N);
+                const unsigned off = (unsigned)((wtap * g.cb + n) * g.cs + cc) * 4u;
+                ld4(rsrc_b, ok ? off : kOutOfRange, b_reg[ps]);
             }
         } else {
             const int n = n0 + 2 * b_rc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kt * BK + b_kq * 4 + j;
-                const bool ok = b_on && (k < kend) && (n < N);
-                const long off = (long)k * N + n;
-                const float2 v = *reinterpret_cast<const float2*>(p.b + (ok ? off : 0L));
-                b_reg[j][0] = v.x; b_reg[j][1] = v.y;
-                b_ok[j] = ok;
+                const bool ok = b_on & (k < kend) & (n < N);
+                const unsigned off = (unsigned)(k * N + n) * 4u;
+                ld2(rsrc_b, ok ? off : kOutOfRange, b_reg[j]);
             }
         }
     };
@@ -225,39 +241,31 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
         *reinterpret_cast<uint2*>(q + 2 * part_bytes) = make_uint2(l01, l23);
     };
 
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, const AReg& a_reg) {
         unsigned char* As = smem_raw + buf * STAGE;
         if constexpr (A_TRANS) {
 #pragma unroll
-            for (int ps = 0; ps < A_PASS; ++ps) {
-                const bool ok = a_ok[ps];
-                put(As, PA, GA, t_kq, t_r + ps * 64, ok ? a_reg[ps][0] : 0.f, ok ? a_reg[ps][1] : 0.f,
-                    ok ? a_reg[ps][2] : 0.f, ok ? a_reg[ps][3] : 0.f);
-            }
+            for (int ps = 0; ps < A_PASS; ++ps)
+                put(As, PA, GA, t_kq, t_r + ps * 64, a_reg[ps][0], a_reg[ps][1], a_reg[ps][2], a_reg[ps][3]);
         } else {
             if (a_on) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    put(As, PA, GA, a_kq, e * (BM / 2) + a_rc, a_ok[0] ? a_reg[0][e] : 0.f, a_ok[1] ? a_reg[1][e] : 0.f,
-                        a_ok[2] ? a_reg[2][e] : 0.f, a_ok[3] ? a_reg[3][e] : 0.f);
+                    put(As, PA, GA, a_kq, e * (BM / 2) + a_rc, a_reg[0][e], a_reg[1][e], a_reg[2][e], a_reg[3][e]);
             }
         }
     };
-    auto store_b = [&](int buf) {
+    auto store_b = [&](int buf, const BReg& b_reg) {
         unsigned char* Bs = smem_raw + buf * STAGE + 3 * PA;
         if constexpr (B_TRANS) {
 #pragma unroll
-            for (int ps = 0; ps < B_PASS; ++ps) {
-                const bool ok = b_ok[ps];
-                put(Bs, PB, GB, t_kq, t_r + ps * 64, ok ? b_reg[ps][0] : 0.f, ok ? b_reg[ps][1] : 0.f,
-                    ok ? b_reg[ps][2] : 0.f, ok ? b_reg[ps][3] : 0.f);
-            }
+            for (int ps = 0; ps < B_PASS; ++ps)
+                put(Bs, PB, GB, t_kq, t_r + ps * 64, b_reg[ps][0], b_reg[ps][1], b_reg[ps][2], b_reg[ps][3]);
         } else {
             if (b_on) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    put(Bs, PB, GB, b_kq, e * (BN / 2) + b_rc, b_ok[0] ? b_reg[0][e] : 0.f, b_ok[1] ? b_reg[1][e] : 0.f,
-                        b_ok[2] ? b_reg[2][e] : 0.f, b_ok[3] ? b_reg[3][e] : 0.f);
+                    put(Bs, PB, GB, b_kq, e * (BN / 2) + b_rc, b_reg[0][e], b_reg[1][e], b_reg[2][e], b_reg[3][e]);
             }
         }
     };
@@ -274,49 +282,72 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     const int frag_a = kh2 * GA + (wm * (BM / WM) + (lane & 31)) * 16;
     const int frag_b = kh2 * GB + (wn * (BN / WN) + (lane & 31)) * 16;
 
-    if (kt0 < kt1) {
-        // Software pipeline, one barrier per slice (as in igemm_kernel): slice kt is multiplied out of
-        // LDS buffer `buf` while slice kt+1 (in registers) is split and written to the other buffer
-        // and the global loads of slice kt+2 are issued.
-        load_a(kt0);
-        load_b(kt0);
-        store_a(0);
-        store_b(0);
-        load_a(kt0 + 1);
-        load_b(kt0 + 1);
-        __syncthreads();
-        int buf = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const unsigned char* As = smem_raw + buf * STAGE;
-            const unsigned char* Bs = As + 3 * PA;
-            bf16x8 af[3][TM], bf[3][TN];
+    // One slice: multiply slice `kt` out of LDS buffer `buf`; meanwhile split the slice held in
+    // (ra, rb) -- slice kt+1, fetched two slices ago -- into the other buffer and refill (ra, rb)
+    // with slice `next` (= kt+3), which therefore has two slices of MFMAs to land.
+    auto slice = [&](int buf, AReg& ra, BReg& rb, int next) {
+        const unsigned char* As = smem_raw + buf * STAGE;
+        const unsigned char* Bs = As + 3 * PA;
+        bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(As + s * PA + frag_a + i * 32 * 16);
+            for (int i = 0; i < TM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(As + s * PA + frag_a + i * 32 * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(Bs + s * PB + frag_b + j * 32 * 16);
+            for (int j = 0; j < TN; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(Bs + s * PB + frag_b + j * 32 * 16);
+        }
+        store_a(buf ^ 1, ra);
+        store_b(buf ^ 1, rb);
+        load_a(next, ra);
+        load_b(next, rb);
+        // six of the nine part products, smallest first: l*h, h*l, m*m, m*h, h*m, h*h
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
+                acc[i][j] = c;
             }
-            store_a(buf ^ 1);
-            store_b(buf ^ 1);
-            load_a(kt + 2);
-            load_b(kt + 2);
-            // six of the nine part products, smallest first: l*h, h*l, m*m, m*h, h*m, h*h
+        // Interleave: the matrix pipe needs 32 cycles per MFMA of which the issue port is busy for 8, so
+        // about six vector instructions fit behind each one; left alone the scheduler clusters the
+        // MFMAs behind the staging work.
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);   // the fragment reads
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-            __syncthreads();
-            buf ^= 1;
+        for (int t = 0; t < 6 * TM * TN; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);  // vector ALU
+            if (t % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS store
+            if (t % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (kt0 < kt1) {
+        // Software pipeline with two register sets and two LDS buffers, one barrier per slice
+        // (slices past the end load zeros and are never multiplied).
+        AReg a0, a1;
+        BReg b0, b1;
+        load_a(kt0, a0);
+        load_b(kt0, b0);
+        load_a(kt0 + 1, a1);
+        load_b(kt0 + 1, b1);
+        store_a(0, a0);
+        store_b(0, b0);
+        load_a(kt0 + 2, a0);
+        load_b(kt0 + 2, b0);
+        __syncthreads();
+        // two slices per trip keep the register sets and LDS buffers compile-time; an odd slice count
+        // multiplies one slice of zeros at the end
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            slice(0, a1, b1, kt + 3);
+            slice(1, a0, b0, kt + 4);
         }
     }
 
