@@ -18,7 +18,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
+SPLIT_PRODUCTS = 6                 # bf16 part products per fp32 product in the default contraction arithmetic
 BATCH = 64
 
 
@@ -129,6 +131,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="one GPU only: run the data-parallel path (segmented graphs + RCCL all-reduce) on a one-rank group")
+    ap.add_argument("--exact-f32", action="store_true",
+                    help="keep every contraction on the fp32 MFMA instead of the bf16 MFMA on split fp32 operands")
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
     args = ap.parse_args()
 
@@ -161,6 +165,8 @@ def main():
 
     from gan_amd import _lib, autotune
     from gan_amd.dcgan import DCGAN
+    if args.exact_f32:
+        _lib.lib.gan_set_exact_f32(1)
     autotune.enable(not args.no_autotune)   # plans are tuned during model construction (eager), before capture
 
     model = DCGAN(None, dcgan64_opts(seed=0), world_size=world, process_group=pg, load_data=False)
@@ -204,9 +210,19 @@ def main():
             model.train_iteration(*pool[i % len(pool)])
         ms, flops, calls, per = tm.summary()
     achieved = flops / (ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "igemm_kernel (+ reduce_slabs_kernel) over the %d contraction calls of one iteration" % (calls // timer_iters),
+    exact = bool(_lib.lib.gan_get_exact_f32())
+    # `achieved` counts the ALGORITHMIC fp32 FLOP of the convolutions.  The default arithmetic forms every
+    # fp32 product from six bf16 x bf16 part products on the bf16 matrix pipe, so the MFMA ceiling for
+    # algorithmic FLOP is the bf16 peak / 6; with --exact-f32 it is the fp32 MFMA peak.
+    peak = FP32_MFMA_PEAK_TFLOPS if exact else BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": ("igemm_kernel" if exact else "igemm_split_kernel") +
+                      " (+ reduce_slabs_kernel) over the %d contraction calls of one iteration" % (calls // timer_iters),
+            "arithmetic": ("fp32 MFMA" if exact else
+                           "fp32 operands split exactly into 3 bf16 parts, 6 of the 9 part products on the bf16 MFMA, "
+                           "fp32 accumulation (error at the fp32 rounding level); peak = bf16 dense peak / 6"),
+            "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "flop_per_step": round(flops / timer_iters / 1e9, 2), "kernel_ms_per_step": round(ms / timer_iters, 3)}
     if args.detail and rank == 0:
         for k, (n, t_ms, fl) in sorted(per.items(), key=lambda kv: -kv[1][1]):
@@ -229,7 +245,7 @@ def main():
                                    "results identical to re-running it)",
                        "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},
             "roofline": roof,
-            "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / peak, 4),
             "losses_last_step": {k: round(v, 5) for k, v in losses.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

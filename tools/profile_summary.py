@@ -34,13 +34,13 @@ def main():
         d[0] += 1
         d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     total = sum(d[1] for d in agg.values())
-    contraction = sum(d[1] for k, d in agg.items() if k.startswith(("igemm_kernel", "reduce_slabs", "tprop_thin")))
+    contraction = sum(d[1] for k, d in agg.items() if k.startswith(("igemm_kernel", "igemm_split_kernel", "reduce_slabs", "tprop_thin")))
     lines = ["# Kernel statistics of the timed region (%d graph replays)" % steps, "",
              "Source: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup 2 --no-cpu-baseline`; "
              "only the kernels of the %d timed replays are counted (%d launches, %.1f per iteration)."
              % (steps, steps, len(sel), len(sel) / steps), "",
              "Wall time of the region %.3f ms = %.3f ms per iteration; summed kernel time %.3f ms per iteration; "
-             "contraction family (igemm_kernel + reduce_slabs + tprop_thin) %.3f ms per iteration."
+             "contraction family (igemm_kernel + igemm_split_kernel + reduce_slabs + tprop_thin) %.3f ms per iteration."
              % (wall, wall / steps, total / 1e3 / steps, contraction / 1e3 / steps), "",
              "| kernel | launches / iteration | us / iteration | avg us | % of kernel time |", "|---|---|---|---|---|"]
     for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
