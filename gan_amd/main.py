@@ -188,9 +188,7 @@ def main(opts):
         if opts.model in ('DCGAN', 'CycleGAN'):
             model.train()           # MNIST idx files / image files under ./data, as in the reference
         else:
-            raise Exception("training Text2Image from files needs the flowers caption / image pickles of the "
-                            "reference's data scripts: call model.train(images, captions) from Python or use "
-                            "--synthetic_iters")
+            return model.train_from_files()     # <data_dir>/flowers/jpg + caption files, as in the reference
     elif opts.phase == 'valid':
         raise Exception("phase 'valid' is not used by the reference's GAN models")
     else:

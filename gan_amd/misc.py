@@ -55,6 +55,20 @@ def save_images(images, size, image_path):
     return imsave(inverse_transform(images), size, image_path)
 
 
+def load_image_array(image_file, image_size, rng=np.random):
+    """utils/image_processing.py:35-52 (the Text2Image loader): RGB (grey images repeated over three
+    channels), resized to image_size x image_size as floats in [0, 1] -- skimage.transform.resize's
+    output range -- and mirrored with probability 0.5.  Bilinear, like skimage's default order 1."""
+    with Image.open(image_file) as im:
+        img = np.asarray(im.convert('RGB'), dtype=np.float32) / 255.0
+    planes = [np.asarray(Image.fromarray(img[:, :, c], mode='F').resize((image_size, image_size), resample=Image.BILINEAR))
+              for c in range(3)]
+    img_resized = np.stack(planes, axis=2)
+    if rng.random() > 0.5:
+        img_resized = np.fliplr(img_resized)
+    return np.clip(img_resized, 0.0, 1.0).astype('float32')
+
+
 # ------------------------------------------------------------------------------------ DCGAN inputs
 def center_crop(x, crop_h, crop_w=None, resize_h=64, resize_w=64):
     """misc.py:72-80"""

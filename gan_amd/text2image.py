@@ -3,10 +3,13 @@ generator (text2image.py:175-198), sampler (:148-172), discriminator (:201-222),
 losses of build_model (:73-128) and the per-batch schedule of train (:243-279): one D update over
 (real, right text) / (wrong image, right text) / (fake, right text), then two G updates.
 
-The data side of the reference (h5py / skimage loaders, :287-417) is host code outside the hot
-path; `train()` here takes in-memory arrays.
+`train()` takes in-memory arrays; `train_from_files()` follows the reference's flowers pipeline
+(load_training_data :287-322, get_training_batch :389-417) for the DS-SJE caption files, which are
+plain .npy arrays.  The skip-thought captions live in an HDF5 file and need h5py.
 """
+import glob
 import os
+import random
 
 import numpy as np
 import torch
@@ -289,6 +292,95 @@ class Text2Image(object):
                     return
             if i % 5 == 0:
                 self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))
+
+    # ---------------------------------------------------------------------------------- flowers files
+    def load_training_data(self, data_dir=None, dataset=None, seed=None):
+        """text2image.py:287-322 for dataset 'flowers': {'image_list', 'captions', 'data_length'}.
+
+        DSSJE: captions are <data_dir>/flowers_caption_icml/<class>/<image>.npy, each [captions, 1024]
+        (:303-316).  The reference takes its image list from the keys of flower_tv.hdf5 even then; the
+        same names are the .npy stems, so the list is built from those when h5py is not there.  The
+        first 75 % of the sorted list is the training split, shuffled (:296-298)."""
+        data_dir = data_dir or self.data_dir
+        dataset = dataset or self.dataset
+        if dataset != 'flowers':
+            raise NotImplementedError("only the flowers files are read here; MS-COCO batches come as arrays (train())")
+        captions, image_list = {}, None
+        h5_path = os.path.join(data_dir, 'flower_tv.hdf5')
+        if self.textEncoder == 'skipthought' or os.path.exists(h5_path):
+            try:
+                import h5py
+            except ImportError:
+                if self.textEncoder == 'skipthought':
+                    raise RuntimeError("skip-thought captions are stored in %s, which needs h5py" % h5_path)
+                h5py = None
+            if h5py is not None:
+                with h5py.File(h5_path, 'r') as data:
+                    captions = {k: np.array(v) for k, v in data.items()}
+                image_list = sorted(captions)
+        if self.textEncoder == 'DSSJE':
+            icml = os.path.join(data_dir, 'flowers_caption_icml')
+            captions = {}
+            for classname in sorted(os.listdir(icml)):
+                if os.path.isdir(os.path.join(icml, classname)):
+                    for filename in glob.glob(os.path.join(icml, classname, '*.npy')):
+                        captions[os.path.basename(filename[0:-4]) + '.jpg'] = np.load(filename, allow_pickle=False)
+            if image_list is None:
+                image_list = sorted(captions)
+        img_75 = int(len(image_list) * 0.75)
+        training_image_list = image_list[0:img_75]
+        random.Random(seed).shuffle(training_image_list)
+        return {'image_list': training_image_list, 'captions': captions, 'data_length': len(training_image_list)}
+
+    def get_training_batch(self, batch_no, loaded_data, data_dir=None, rng=random):
+        """text2image.py:389-417 (flowers): real images in list order, a uniformly drawn wrong image and
+        one of the image's nCapsPerImage captions per sample, z ~ U(-1, 1).  Images are floats in [0, 1]."""
+        from .misc import load_image_array
+        data_dir = data_dir or self.data_dir
+        bs, s = self.batch_size, self.image_size
+        real_images = np.zeros((bs, s, s, 3), np.float32)
+        wrong_images = np.zeros((bs, s, s, 3), np.float32)
+        captions = np.zeros((bs, self.caption_vector_length), np.float32)
+        names = loaded_data['image_list']
+        image_files = []
+        for cnt, i in enumerate(range(batch_no * bs, batch_no * bs + bs)):
+            idx = i % len(names)
+            image_file = os.path.join(data_dir, 'flowers/jpg/' + names[idx])
+            real_images[cnt] = load_image_array(image_file, s, rng)
+            wrong_image_id = rng.randint(0, len(names) - 1)
+            wrong_images[cnt] = load_image_array(os.path.join(data_dir, 'flowers/jpg/' + names[wrong_image_id]), s, rng)
+            random_caption = rng.randint(0, self.nCapsPerImage - 1)     # randint arguments are inclusive
+            captions[cnt] = loaded_data['captions'][names[idx]][random_caption][0:self.caption_vector_length]
+            image_files.append(image_file)
+        z_noise = np.asarray([[rng.uniform(-1, 1) for _ in range(self.z_dim)] for _ in range(bs)], np.float32)
+        return real_images, wrong_images, captions, z_noise, image_files
+
+    def train_from_files(self, data_dir=None, max_iters=None, seed=None):
+        """The training loop of text2image.py:224-285 over the flowers files."""
+        dev = self.store.device
+        rng = random.Random(seed)
+        loaded = self.load_training_data(data_dir, self.dataset, seed)
+        if loaded['data_length'] == 0:
+            raise RuntimeError("no flowers training images found under %s" % (data_dir or self.data_dir))
+        n_batch = loaded['data_length'] // self.batch_size
+        iters, out = 0, None
+        for i in range(self.nEpochs):
+            batch_no = 0
+            while batch_no * self.batch_size < loaded['data_length']:
+                real, wrong, cap, z, _ = self.get_training_batch(batch_no, loaded, data_dir, rng)
+                out = self.train_iteration(*[torch.from_numpy(a).to(dev) for a in (real, wrong, cap, z)])
+                d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
+                print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
+                    i, batch_no, n_batch, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
+                batch_no += 1
+                if (batch_no % self.save_every_batch) == 0:
+                    self.save(self.checkpoint_dir, batch_no)
+                iters += 1
+                if max_iters is not None and iters >= max_iters:
+                    return out
+            if i % 5 == 0:
+                self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))
+        return out
 
     @property
     def model_dir(self):

@@ -95,3 +95,26 @@ def test_training_from_image_files_and_sample_grids(tmp_path):
     out = c.train(files[:3], files[3:6], sample_every=2)
     assert all(np.isfinite(float(v)) for v in out.values())
     assert len(list((tmp_path / "smp2").glob("A_*.jpg"))) == 1 and all(opt.steps_taken == 3 for opt in c.optims.values())
+
+
+@pytest.mark.gpu
+def test_text2image_trains_from_the_flowers_files(tmp_path):
+    """`--model Text2Image --dataset flowers --textEncoder DSSJE` reads <data_dir>/flowers/jpg and the
+    DS-SJE caption .npy files like the reference (text2image.py:287-322, 389-417) and runs its schedule."""
+    from PIL import Image
+    from gan_amd.main import main
+    rng = np.random.default_rng(0)
+    (tmp_path / "flowers" / "jpg").mkdir(parents=True)
+    (tmp_path / "flowers_caption_icml" / "class_00001").mkdir(parents=True)
+    for i in range(12):
+        name = "image_%05d" % i
+        Image.fromarray(rng.integers(0, 256, (70, 80, 3)).astype(np.uint8)).save(str(tmp_path / "flowers" / "jpg" / (name + ".jpg")))
+        np.save(str(tmp_path / "flowers_caption_icml" / "class_00001" / (name + ".npy")),
+                rng.standard_normal((10, 1024)).astype(np.float32))
+    o = parse(("--model Text2Image --dataset flowers --input_height 64 --textEncoder DSSJE --batch_size 4 --gf_dim 4 "
+               "--df_dim 4 --t_dim 8 --caption_vector_length 12 --z_dim 10 --nEpochs 1").split()
+              + ["--data_dir", str(tmp_path), "--checkpoint_dir", str(tmp_path / "ck"), "--sample_dir", str(tmp_path / "smp")])
+    out = main(o)           # 9 training images / batch 4 -> 3 batches
+    assert all(np.isfinite(float(out[k])) for k in ('d_loss1', 'd_loss2', 'd_loss3', 'g_loss_1', 'g_loss_2'))
+    assert out['generator'].shape == (4, 64, 64, 3)
+    assert (tmp_path / "ck" / "Text2Image_flowers_4_64").exists()       # the end-of-epoch checkpoint

@@ -71,3 +71,39 @@ def test_cyclegan_pair_loading(tmp_path):
     ta, tb = preprocess_A_and_B(a, a, load_size=36, fine_size=32, is_test=True)
     assert ta.shape == (32, 32, 3) and np.array_equal(ta, tb)
     assert load_test_data(pa, fine_size=16).shape == (16, 16, 3)
+
+
+def test_text2image_flowers_file_pipeline(tmp_path, monkeypatch):
+    """load_training_data / get_training_batch of the Text2Image model over a tiny flowers tree
+    (DS-SJE captions as .npy, jpg images): list split and shuffle, caption choice, image range.
+    Host logic only: the model object is created without building its networks."""
+    import random
+    from PIL import Image
+    from gan_amd.text2image import Text2Image
+    rng = np.random.default_rng(0)
+    (tmp_path / "flowers" / "jpg").mkdir(parents=True)
+    for cls in ("class_00001", "class_00002"):
+        (tmp_path / "flowers_caption_icml" / cls).mkdir(parents=True)
+    names = ["image_%05d" % i for i in range(8)]
+    caps = {}
+    for i, n in enumerate(names):
+        Image.fromarray(rng.integers(0, 256, (40 + i, 50, 3)).astype(np.uint8)).save(str(tmp_path / "flowers" / "jpg" / (n + ".jpg")))
+        caps[n] = rng.standard_normal((10, 1024)).astype(np.float32)
+        np.save(str(tmp_path / "flowers_caption_icml" / ("class_0000%d" % (1 + i % 2)) / (n + ".npy")), caps[n])
+    m = Text2Image.__new__(Text2Image)
+    m.textEncoder, m.data_dir, m.dataset, m.batch_size, m.image_size = 'DSSJE', str(tmp_path), 'flowers', 4, 16
+    m.caption_vector_length, m.nCapsPerImage, m.z_dim = 12, 10, 5
+    data = m.load_training_data(seed=3)
+    assert data['data_length'] == 6 and sorted(data['image_list']) == [n + ".jpg" for n in names[:6]]   # first 75 %
+    assert set(data['captions']) == {n + ".jpg" for n in names}
+    real, wrong, cap, z, files = m.get_training_batch(1, data, rng=random.Random(5))
+    assert real.shape == wrong.shape == (4, 16, 16, 3) and cap.shape == (4, 12) and z.shape == (4, 5)
+    assert 0.0 <= real.min() and real.max() <= 1.0 and np.abs(z).max() <= 1.0
+    # batch 1 of size 4 over 6 images wraps around the list (text2image.py:399-400)
+    want = [data['image_list'][i % 6] for i in range(4, 8)]
+    assert [f.split('/')[-1] for f in files] == want
+    for row, f in zip(cap, files):
+        stem = f.split('/')[-1][:-4]
+        assert any(np.array_equal(row, caps[stem][k][:12]) for k in range(10))
+    with pytest.raises(NotImplementedError):
+        m.load_training_data(dataset='mscoco')
