@@ -11,7 +11,7 @@ def timeit(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for cfg, splits in [(0, 8), (0, 12), (0, 16), (2, 2), (2, 3), (2, 4)]:
+for cfg, splits in [(0, 8), (0, 16), (4, 4), (4, 8), (4, 16), (5, 4), (5, 8), (6, 2), (6, 4)]:
     os.environ["GAN_HIP_FORCE_CFG"] = str(cfg); os.environ["GAN_HIP_FORCE_SPLITS"] = str(splits)
     xs, ys = [], []
     for cb in (32, 64, 128, 256, 512):
@@ -23,6 +23,7 @@ for cfg, splits in [(0, 8), (0, 12), (0, 16), (2, 2), (2, 3), (2, 4)]:
         slices = 25 * cb / 16 / splits
         xs.append(slices); ys.append(us)
     a, b = np.polyfit(xs, ys, 1)
-    tiles = (4096 // (128 if cfg == 0 else 64)) * (256 // (128 if cfg == 0 else 64))
+    bm, bn = {0: (128, 128), 2: (64, 64), 4: (128, 128), 5: (128, 64), 6: (64, 64)}[cfg]
+    tiles = (4096 // bm) * (256 // bn)
     print("cfg %d splits %2d blocks %4d: us vs slices/block %s -> %.2f us/slice, intercept %.1f us (incl. reduce pass)" % (
         cfg, splits, tiles * splits, ["%.0f:%.1f" % p for p in zip(xs, ys)], a, b), flush=True)
