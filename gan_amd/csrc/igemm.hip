@@ -892,6 +892,19 @@ static void launch_vec(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, 1, 1>), grid, dim3(256), 0, s, a);
 }
 
+// The split kernel's cheap gather arithmetic needs 16-channel alignment of the gathered image (FPROP: big
+// side, TPROP: small side) or, for WGRAD, a small-image width that is a multiple of 4.
+template <int MODE, int BM, int BN>
+static void launch_split(const IgemmArgs& a, dim3 grid, hipStream_t s) {
+    const gan_conv_geom& g = a.g;
+    const bool fast = (MODE == MODE_FPROP) ? (g.cb % 16 == 0)
+                    : (MODE == MODE_TPROP) ? (g.cs % 16 == 0) : (g.ws % 4 == 0);
+    if (fast && !getenv("GAN_HIP_SLOW_GATHER"))
+        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false>), grid, dim3(256), 0, s, a);
+}
+
 template <int MODE>
 static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_t s) {
     switch (pl.cfg) {
@@ -899,9 +912,9 @@ static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         case 1: launch_vec<MODE, 128, 64, 2, 2>(a, pl, grid, s); break;
         case 2: launch_vec<MODE, 64, 64, 2, 2>(a, pl, grid, s); break;
         case 3: launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break;
-        case 4: hipLaunchKernelGGL((igemm_split_kernel<MODE, 128, 128, 2, 2>), grid, dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL((igemm_split_kernel<MODE, 128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((igemm_split_kernel<MODE, 64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
+        case 4: launch_split<MODE, 128, 128>(a, grid, s); break;
+        case 5: launch_split<MODE, 128, 64>(a, grid, s); break;
+        default: launch_split<MODE, 64, 64>(a, grid, s); break;
     }
 }
 

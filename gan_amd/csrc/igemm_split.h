@@ -51,7 +51,13 @@ __device__ __forceinline__ int unpermute(int pos) {
     return 2 * (pos % (ROWS / 2)) + pos / (ROWS / 2);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+// FAST selects the cheap gather arithmetic (the host checks its condition):
+//   FPROP / TPROP: the gathered image's channel count is a multiple of 16, so a 16-deep slice lies
+//     inside ONE filter tap: the tap decode depends only on the slice number and runs on the scalar
+//     unit, and a thread's offset is a constant of the thread plus a per-slice scalar;
+//   WGRAD: the small image's width is a multiple of 4, so the 4 consecutive pixels a thread gathers
+//     share an image row: one pixel decode per slice instead of four.
+template <int MODE, int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     static_assert(WM * WN == 4, "four waves per block");
     static_assert(BM % 64 == 0 && BN % 64 == 0, "tile sides are multiples of 64");
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     constexpr int PA = 2 * GA, PB = 2 * GB;                // one part of a 16-deep slice
     constexpr int STAGE = 3 * (PA + PB);
     // vector instructions of one slice (split, address arithmetic) per MFMA of that slice
-    constexpr int kValuPerMfma = (TM * TN >= 4) ? 7 : (TM * TN == 2 ? 11 : 20);
+    constexpr int kValuPerMfma = (TM * TN >= 4) ? (FAST ? 5 : 7) : (TM * TN == 2 ? (FAST ? 8 : 11) : (FAST ? 14 : 20));
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[2 * STAGE];
 
     const int tid = threadIdx.x;
@@ -149,6 +155,27 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     const int b_rc = (btc >> 1) % (BN / 2);
     const int b_kq = ((btc / BN) << 1) | (btc & 1);
 
+    // thread-constant byte offsets of the fast paths (a per-slice scalar is added to them)
+    unsigned a_rb[A_TRANS ? A_PASS : 1], b_rb[B_TRANS ? B_PASS : 1], b_cj[4];
+    bool b_nvalid[B_TRANS ? B_PASS : 1];
+    if constexpr (A_TRANS) {
+#pragma unroll
+        for (int ps = 0; ps < A_PASS; ++ps)
+            a_rb[ps] = (unsigned)((a_base[ps] + a_y0[ps] * SW + a_x0[ps]) * SC + t_kq * 4) * 4u;
+    }
+    if constexpr (B_TRANS) {
+#pragma unroll
+        for (int ps = 0; ps < B_PASS; ++ps) {
+            const int n = n0 + t_r + ps * 64;
+            b_nvalid[ps] = n < N;
+            b_rb[ps] = (unsigned)(n * g.cs + t_kq * 4) * 4u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_cj[j] = (unsigned)((b_kq * 4 + j) * N + n0 + 2 * b_rc) * 4u;
+    }
+    const bool b_pair_valid = b_on & (n0 + 2 * b_rc < N);
+
     typedef float AReg[A_PASS][A_W];
     typedef float BReg[B_PASS][B_W];
     const __amdgpu_buffer_rsrc_t rsrc_a =
@@ -166,7 +193,23 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     };
 
     auto load_a = [&](int kt, AReg& a_reg) {
-        if constexpr (A_TRANS) {
+        if constexpr (A_TRANS && FAST) {
+            // scalar: the slice's tap and first channel
+            const unsigned k0 = (unsigned)__builtin_amdgcn_readfirstlane(kt * BK);
+            const int tapc = fdiv(k0, dSC);
+            const int cc0 = k0 - tapc * SC;
+            const int ta = fdiv(tapc, dTW);
+            const int tb = tapc - ta * (int)dTW.d;
+            const int sgn = (MODE == MODE_TPROP) ? -1 : 1;
+            const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((sgn * (ta * SW + tb) * SC + cc0) * 4);
+            const bool kv = (int)k0 + t_kq * 4 < kend;
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                const int iy = a_y0[ps] + sgn * ta, ix = a_x0[ps] + sgn * tb;
+                const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
+                ld4(rsrc_a, ok ? a_rb[ps] + u : kOutOfRange, a_reg[ps]);
+            }
+        } else if constexpr (A_TRANS) {
             const int k = kt * BK + t_kq * 4;
             const bool kv = k < kend;
             const unsigned uk = kv ? (unsigned)k : 0u;
@@ -181,6 +224,24 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
                 const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
                 const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
                 ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
+            }
+        } else if constexpr (FAST) {
+            // the thread's 4 pixels are consecutive in one row of the small image
+            const int k = kt * BK + a_kq * 4;
+            const bool kv = (k < kend) & a_mvalid;
+            const unsigned uk = kv ? (unsigned)k : 0u;
+            const int img = fdiv(uk, p.d_hsws);
+            const int rem = uk - img * (int)p.d_hsws.d;
+            const int oy = fdiv(rem, p.d_ws);
+            const int ox = rem - oy * g.ws;
+            const int iy = oy * g.sh + a_kh - g.pt, ix0 = ox * g.sw + a_kw - g.pl;
+            const bool rowok = kv & ((unsigned)iy < (unsigned)g.hb);
+            const unsigned off0 = (unsigned)(((img * g.hb + iy) * g.wb + ix0) * g.cb + a_c) * 4u;
+            const unsigned step = (unsigned)(g.sw * g.cb) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = rowok & ((unsigned)(ix0 + j * g.sw) < (unsigned)g.wb);
+                ld2(rsrc_a, ok ? off0 + j * step : kOutOfRange, a_reg[j]);
             }
         } else {
 #pragma unroll
@@ -201,7 +262,18 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     };
 
     auto load_b = [&](int kt, BReg& b_reg) {
-        if constexpr (B_TRANS) {
+        if constexpr (B_TRANS && FAST) {
+            const unsigned k0 = (unsigned)__builtin_amdgcn_readfirstlane(kt * BK);
+            const int tapc = fdiv(k0, p.d_cs);
+            const int cc0 = k0 - tapc * g.cs;
+            const int ta = fdiv(tapc, cl.d_kwc);
+            const int tb = tapc - ta * cl.kwc;
+            const int wtap = (cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb);
+            const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((wtap * g.cb * g.cs + cc0) * 4);
+            const bool kv = (int)k0 + t_kq * 4 < kend;
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps) ld4(rsrc_b, (kv & b_nvalid[ps]) ? b_rb[ps] + u : kOutOfRange, b_reg[ps]);
+        } else if constexpr (B_TRANS) {
             const int k = kt * BK + t_kq * 4;
             const bool kv = k < kend;
             const unsigned uk = kv ? (unsigned)k : 0u;
@@ -218,14 +290,11 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
                 ld4(rsrc_b, ok ? off : kOutOfRange, b_reg[ps]);
             }
         } else {
-            const int n = n0 + 2 * b_rc;
+            // row-major [K][N]: a constant of the thread per k row plus the slice's scalar offset
+            const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane(kt * BK * N * 4);
+            const int kb = kt * BK + b_kq * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = kt * BK + b_kq * 4 + j;
-                const bool ok = b_on & (k < kend) & (n < N);
-                const unsigned off = (unsigned)(k * N + n) * 4u;
-                ld2(rsrc_b, ok ? off : kOutOfRange, b_reg[j]);
-            }
+            for (int j = 0; j < 4; ++j) ld2(rsrc_b, (b_pair_valid & (kb + j < kend)) ? b_cj[j] + u : kOutOfRange, b_reg[j]);
         }
     };
 
@@ -322,8 +391,6 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
         for (int t = 0; t < 6 * TM * TN; ++t) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);  // vector ALU
-            if (t % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS store
-            if (t % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
         }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);

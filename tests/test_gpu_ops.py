@@ -115,6 +115,12 @@ SPLIT_CONVS = [
     (5, 4, 4, 24, 16, 1, 1, 'SAME'),        # 1x1: K = 24
     (1, 10, 10, 8, 8, 3, 1, 'VALID'),
     (2, 16, 16, 12, 4, 5, 1, 'SAME'),       # transposed contraction with 12 output channels
+    # channel counts / widths that take the cheap gather arithmetic (16-channel aligned gathered image, small
+    # width a multiple of 4), still with ragged tiles
+    (3, 14, 14, 32, 76, 5, 2, 'SAME'),      # FPROP fast (cb = 32), TPROP slow (cs = 76), WGRAD slow (ws = 7)
+    (1, 17, 12, 16, 144, 3, 1, 'SAME'),     # all three fast: cb = 16, cs = 144, ws = 12; M = 204
+    (2, 9, 16, 48, 32, 5, 2, 'SAME'),       # all three fast, odd height, pad (1, 2)
+    (1, 11, 7, 20, 48, 3, 1, 'SAME'),       # only TPROP fast (cs = 48)
 ]
 
 
@@ -489,6 +495,36 @@ def test_autotuned_plans_keep_parity(L):
     finally:
         autotune.reset()
     assert autotune.report() == {}
+
+
+@pytest.mark.parametrize("case", [(3, 14, 16, 32, 80, 5, 2), (1, 17, 12, 16, 144, 3, 1), (2, 16, 16, 64, 128, 5, 2)])
+def test_split_kernel_gather_variants_agree_bitwise(L, case, monkeypatch):
+    """The cheap gather arithmetic of the split kernels (scalar tap decode, one pixel decode per four) only
+    changes how addresses are formed: results are bit-identical to the general path."""
+    from gpu_util import geom_for
+    n, h, w, cb, cs, k, s = case
+    g = geom_for(n, h, w, cb, cs, k, s, 'SAME')
+    gp = ctypes.byref(g)
+    x = torch.randn(n, h, w, cb, device='cuda')
+    wt = torch.randn(k, k, cb, cs, device='cuda') * 0.05
+    dy = torch.randn(n, g.hs, g.ws, cs, device='cuda')
+    outs = []
+    for slow in (False, True):
+        if slow:
+            monkeypatch.setenv("GAN_HIP_SLOW_GATHER", "1")
+        y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(wt)
+        wp, wn = _ws(L, g)
+        st = L.stream()
+        c, sp, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.check(L.lib.gan_conv_plan_get(0, gp, ctypes.byref(c), ctypes.byref(sp), ctypes.byref(thin)))
+        assert c.value >= 4
+        L.check(L.lib.gan_conv2d_fwd(gp, L.ptr(x), L.ptr(wt), None, L.ptr(y), wp, wn, st))
+        L.check(L.lib.gan_conv2d_dgrad(gp, L.ptr(dy), L.ptr(wt), L.ptr(dx), wp, wn, st))
+        L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(x), L.ptr(dy), L.ptr(dw), None, 0, wp, wn, st))
+        torch.cuda.synchronize()
+        outs.append((y, dx, dw))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_split_bf16_arithmetic_is_as_accurate_as_the_fp32_mfma(L):
