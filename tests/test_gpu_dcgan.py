@@ -265,3 +265,33 @@ def test_staged_backward_with_early_exchange_equals_plain_backward(cond, stacked
         assert SegmentedIteration.active is None
     finally:
         dist.destroy_process_group()
+
+
+def test_default_and_exact_f32_contraction_arithmetic_train_alike():
+    """The default contraction arithmetic (fp32 operands as three exact bf16 parts on the bf16 matrix pipe)
+    against gan_set_exact_f32(1) (fp32 MFMA): the first iteration's losses agree to fp32 rounding, and over
+    20 iterations the two runs drift apart no faster than the GPU drifts from the float64 oracle
+    (the 2e-2 bound of the trajectory test)."""
+    from gan_amd import _lib as L
+    opts = make_opts()
+    _, a, rng = build_pair(opts, seed=31)
+    _, b, _ = build_pair(opts, seed=31)
+    batches = [to_dev(*batch(opts, rng)[:2]) for _ in range(20)]
+    keys = ('d_loss_real', 'd_loss_fake', 'g_loss_1', 'g_loss_2')
+    import ctypes
+    from gpu_util import geom_for
+    c, s, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    g = geom_for(8, 4, 4, 32, 64, 5, 2, 'SAME')                # d_h3 of this small model
+    L.check(L.lib.gan_conv_plan_get(0, ctypes.byref(g), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+    assert c.value >= 4                                         # the default really is the split kernel here
+    try:
+        la = [[float(o[k]) for k in keys] for o in (a.train_iteration(im, z) for im, z in batches)]
+        L.lib.gan_set_exact_f32(1)
+        L.check(L.lib.gan_conv_plan_get(0, ctypes.byref(g), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+        assert c.value < 4
+        lb = [[float(o[k]) for k in keys] for o in (b.train_iteration(im, z) for im, z in batches)]
+    finally:
+        L.lib.gan_set_exact_f32(0)
+    la, lb = np.array(la), np.array(lb)
+    assert np.abs(la[0] - lb[0]).max() <= 2e-5 * max(1.0, np.abs(lb[0]).max()), (la[0], lb[0])
+    assert np.abs(la - lb).max() <= 2e-2, np.abs(la - lb).max(axis=0)
