@@ -177,14 +177,20 @@ class CycleGAN(object):
             optim.begin()
             # the generator being updated needs its pass on tape; the other one only supplies a
             # constant input (tf.gradients prunes it the same way)
+            # the translated image of the direction being trained feeds its discriminator AND the other
+            # generator: ops.fork sums the two gradients
             fake_B = self._first_pass('a2b', real_data, real_A, want_tape=(which == 'a2b'))
+            if which == 'a2b':
+                fake_B, fake_B_d = ops.fork(fake_B)
             fake_A_ = self.generator(fake_B, self.options, True, name="generatorB2A")
             fake_A = self._first_pass('b2a', real_data, real_B, want_tape=(which == 'b2a'))
+            if which == 'b2a':
+                fake_A, fake_A_d = ops.fork(fake_A)
             fake_B_ = self.generator(fake_A, self.options, True, name="generatorA2B")
             if which == 'a2b':
-                gan = self.criterionGAN(self.discriminator(fake_B, self.options, reuse=True, name="discriminatorB"), 1.0)
+                gan = self.criterionGAN(self.discriminator(fake_B_d, self.options, reuse=True, name="discriminatorB"), 1.0)
             else:
-                gan = self.criterionGAN(self.discriminator(fake_A, self.options, reuse=True, name="discriminatorA"), 1.0)
+                gan = self.criterionGAN(self.discriminator(fake_A_d, self.options, reuse=True, name="discriminatorA"), 1.0)
             cyc_a = abs_criterion(real_A, fake_A_, self.L1_lambda)
             cyc_b = abs_criterion(real_B, fake_B_, self.L1_lambda)
             ops.backward([gan, cyc_a, cyc_b])

@@ -53,11 +53,12 @@ def generator_resnet(image, options, reuse=False, name="generator"):
             resBN1 = batch_norm(name=name + '_bn1')
             resBN2 = batch_norm(name=name + '_bn2')
             p = int((ks - 1) / 2)
+            x, skip = ops.fork(x)       # the block's input feeds the convolutions and the skip connection
             y = ops.reflect_pad(x, p)
             y = resBN1(conv2d(y, dim, ks, ks, s, s, padding='VALID', name=name + '_c1'), act='relu')
             y = ops.reflect_pad(y, p)
             # resBN2(...) + x, the residual add fused into the normalisation kernel
-            return resBN2(conv2d(y, dim, ks, ks, s, s, padding='VALID', name=name + '_c2'), residual=x)
+            return resBN2(conv2d(y, dim, ks, ks, s, s, padding='VALID', name=name + '_c2'), residual=skip)
 
         g_e1_bn = batch_norm(name='g_e1_bn')
         g_e2_bn = batch_norm(name='g_e2_bn')

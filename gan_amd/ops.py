@@ -454,6 +454,35 @@ def add(a, b):
     return _AddFn.apply(a, b)
 
 
+class _ForkFn(torch.autograd.Function):
+    """One tensor handed to several consumers: the backward pass sums their gradients with the library's
+    add kernel (left to itself, autograd would accumulate them with a torch operator)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        grads = [_dense(g) for g in grads if g is not None]
+        if not grads:
+            return None, None
+        total = grads[0]
+        for g in grads[1:]:
+            out = torch.empty_like(total)
+            check(lib.gan_add_fwd(ptr(total), ptr(g), ptr(out), total.numel(), stream()))
+            total = out
+        return total, None
+
+
+def fork(x, n=2):
+    """`n` aliases of `x`, one per consumer (a residual connection, a generated image that feeds both a
+    discriminator and the other generator).  Without a backward pass to run it returns `x` n times."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return _ForkFn.apply(x, n)
+
+
 class _ConcatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, rows_per_b):
