@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="one GPU only: run the data-parallel path (segmented graphs + RCCL all-reduce) on a one-rank group")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo only for rehearsing several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--exact-f32", action="store_true",
                     help="keep every contraction on the fp32 MFMA instead of the bf16 MFMA on split fp32 operands")
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
@@ -149,6 +151,8 @@ def main():
                          % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
+    if args.backend == "gloo":
+        local_rank = 0                      # rehearsal: every rank on the one visible GPU
     torch.cuda.set_device(local_rank)
     dist = None
     pg = None
@@ -160,6 +164,8 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
             pg = dist.group.WORLD
+        elif args.backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -194,7 +200,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if args.backend == "gloo" else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = {k: float(v) for k, v in out.items()}
@@ -240,7 +246,8 @@ def main():
                                    "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 and pg is None
-                                                               else "hipGraph segments + RCCL all-reduce"),
+                                                               else "hipGraph segments + %s all-reduce overlapped with the backward pass"
+                                                               % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")),
                        "schedule": "the first G update reuses the D update's generator pass (same z, same weights; "
                                    "results identical to re-running it)",
                        "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},

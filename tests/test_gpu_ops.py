@@ -564,3 +564,19 @@ def test_split_bf16_arithmetic_is_as_accurate_as_the_fp32_mfma(L):
     for e_exact, e_split in zip(errs[1], errs[0]):
         assert e_exact < 5e-6 and e_split < 5e-6, errs
         assert e_split < 4 * e_exact + 2e-7, errs
+
+
+def test_fork_sums_the_gradients_of_its_consumers(L):
+    """ops.fork hands one tensor to several consumers; the backward pass adds their gradients with the
+    library's add kernel.  Without a backward pass to run it is the identity."""
+    from gan_amd import ops
+    x = torch.randn(3, 4, 4, 8, device='cuda', requires_grad=True)
+    a, b, c = ops.fork(x, 3)
+    assert a.data_ptr() == x.data_ptr() and torch.equal(b, x)
+    wa, wb, wc = (torch.randn_like(x) for _ in range(3))
+    torch.autograd.backward([a, b, c], [wa, wb, wc])
+    torch.cuda.synchronize()
+    assert torch.equal(x.grad, (wa + wb) + wc)
+    with torch.no_grad():
+        assert ops.fork(x)[1] is x
+    assert ops.fork(x.detach())[0] is not None and ops.fork(x.detach())[0].requires_grad is False
