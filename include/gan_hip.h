@@ -203,6 +203,12 @@ int gan_linear_as_conv_geom(int rows, int in_dim, int out_dim, gan_conv_geom* g)
 void gan_set_exact_f32(int on);
 int gan_get_exact_f32(void);
 
+/* Environment variables read at call time, for tests and tuning only (none is needed in production):
+ *   GAN_HIP_FORCE_CFG=<0..6>, GAN_HIP_FORCE_SPLITS=<n>  override the plan of every contraction;
+ *   GAN_HIP_NO_THIN=1         keeps thin outputs (<= 4 channels / <= 4 linear outputs) on the MFMA path;
+ *   GAN_HIP_SLOW_GATHER=1     general gather arithmetic in the split kernel (results are bit-identical);
+ *   GAN_HIP_SCALAR_EPILOGUE=1 dword stores instead of the 16-byte epilogue. */
+
 /* ---- utilities ------------------------------------------------------------------------- */
 int gan_fill(float* x, long n, float value, gan_stream_t stream);
 
