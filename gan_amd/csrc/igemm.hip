@@ -817,7 +817,8 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     const int nkt = (K + BK - 1) / BK;
     const long blocks = (long)pl.mt * pl.nt * (mode == MODE_TPROP ? a.ncls : 1);
     int splits = 1;
-    const long target = 768;  // ~3 blocks per CU
+    // one co-resident wave of blocks: the fp32 kernel fits 3 blocks per CU, the split kernel 2
+    const long target = pl.cfg >= kFirstSplitCfg ? 512 : 768;
     if (blocks < target) {
         splits = (int)(target / blocks);
         const int max_by_k = nkt / 8 > 0 ? nkt / 8 : 1;  // keep >= 8 k-slices (128 deep) per split
