@@ -418,7 +418,7 @@ def test_add_fill_concat_reflect(L):
 
 def test_losses(L):
     from gpu_util import assert_close, dev, host
-    for n in (64, 1024, 3 * 32 * 32, 50000):
+    for n in (64, 1024, 3 * 32 * 32, 50000, 50001, 3 * 256 * 256):   # >= 4096 and a multiple of 4: 16-byte path
         x = (RNG.standard_normal(n) * 3).astype(np.float32)
         xd = dev(x)
         loss = torch.zeros(1, device='cuda')
