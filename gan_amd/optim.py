@@ -18,6 +18,7 @@ class AdamOptimizer(object):
         self.group = None
         self.step_dev = None
         self.lr_scratch = None
+        self._early = None      # the early part's exchange in flight (a work handle, or True once done)
 
     def attach(self, group):
         """Bind to a packed variable group (the var_list)."""
@@ -68,7 +69,7 @@ class AdamOptimizer(object):
 
     def _all_reduce_now(self, process_group):
         import torch.distributed as dist
-        early, self._early = getattr(self, '_early', None), None
+        early, self._early = self._early, None
         grads = self.group.grads if early is None else self.group.late_grads()
         try:
             self._sum(grads, process_group)
