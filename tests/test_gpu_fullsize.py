@@ -107,6 +107,63 @@ def test_mnist_conditional_dcgan_full_size_against_oracle():
             assert abs(got[k_] - want[k_]) <= 2e-3 * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
 
 
+def test_dcgan64_full_size_against_oracle():
+    """BASELINE config 1, the benchmarked one: DCGAN 64x64x3, batch 64, gf_dim = df_dim = 64, default
+    contraction arithmetic.  The D update's gradients of the first iteration and the losses of two whole
+    iterations (1 D + 2 G updates each) against the float64 oracle.
+
+    Gradient bars: the layers above the last leaky-relu whose 10^5..10^6 units include one within float32
+    rounding of its kink (d_h3_lin, d_bn3, d_h3_conv, d_bn2/gamma here) agree to 1e-5.  Below such a unit
+    every float32 evaluation -- this library in either arithmetic mode and the oracle run in float32 alike,
+    measured 8e-4 .. 8e-3 on these very inputs -- differs from float64 by the gradient that one unit
+    switches, so the lower layers are held to 2e-2; biases that feed a batch norm are noise on both sides."""
+    from oracle import autodiff as A
+    from oracle import nets
+    from gan_amd.dcgan import DCGAN
+    from gpu_util import check_group_grads, dev
+    opts = argparse.Namespace(model='DCGAN', dataset='celebA', batch_size=64, input_height=108, input_width=108,
+                              output_height=64, output_width=64, y_dim=None, z_dim=100, gf_dim=64, df_dim=64,
+                              gfc_dim=1024, dfc_dim=1024, c_dim=3, lr=0.0002, beta1=0.5, crop=True, nEpochs=1,
+                              train_size=1e8, print_every=1, checkpoint_dir='./checkpoint', seed=0)
+    st = A.Store(seed=5, dtype=np.float64)
+    ref = nets.DCGAN(st, batch_size=64)
+    ref.build(np.zeros((64, 64, 64, 3)), np.zeros((64, 100)))
+    for n in st.values:      # both sides start from the same float32 numbers
+        st.values[n] = st.values[n].astype(np.float32).astype(np.float64)
+    gpu = DCGAN(None, opts, load_data=False)
+    assert list(gpu.store.vars) == list(st.values)
+    gpu.store.load_state_dict(st.values)
+    rng = np.random.default_rng(5)
+    im = rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)
+    z = rng.uniform(-1, 1, (64, 100)).astype(np.float32)
+    # gradients of d_loss w.r.t. d_vars at the initial weights
+    tp = A.Tape(ref.st)
+    lr_, lf_ = ref.d_losses(tp, im.astype(np.float64), z.astype(np.float64))
+    tp.backward(A.add(tp, lr_, lf_))
+    gpu.d_grads(dev(im), dev(z))
+    torch.cuda.synchronize()
+    want_g = tp.grads(ref.d_vars)
+    check_group_grads(gpu.d_group, want_g, tol=2e-2)
+    top = ('d_h3_lin/Matrix', 'd_h3_lin/bias', 'd_bn3/beta', 'd_bn3/gamma', 'd_h3_conv/w', 'd_bn2/gamma')
+    for v in gpu.d_group.variables:
+        if v.name.split('/', 1)[1] in top:
+            from gpu_util import assert_close, host
+            assert_close(host(v.grad), want_g[v.name], "grad " + v.name, tol=1e-5)
+    for it in range(2):
+        want = ref.train_iteration(im.astype(np.float64), z.astype(np.float64))
+        out = gpu.train_iteration(dev(im), dev(z))
+        got = {'d_loss': float(out['d_loss_real']) + float(out['d_loss_fake']),
+               'g_loss_1': float(out['g_loss_1']), 'g_loss_2': float(out['g_loss_2'])}
+        # stated tolerance: 2e-3 on the first iteration's losses, 1e-2 on the second's (Adam's first steps move
+        # every weight by about lr whatever the size of its gradient, which amplifies the float32 differences
+        # of the first iteration; the 200-step trajectory test bounds the growth)
+        tol = 2e-3 if it == 0 else 1e-2
+        for k_ in got:
+            assert abs(got[k_] - want[k_]) <= tol * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
+        im = rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)
+        z = rng.uniform(-1, 1, (64, 100)).astype(np.float32)
+
+
 def _finite_grads(optims):
     for o in optims:
         assert bool(torch.isfinite(o.group.grads).all())
