@@ -136,36 +136,42 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
     }
 }
 
-// One wave per (group, channel).
+// One wave per (group, channel); with `chain_groups` one wave per channel takes the groups one after
+// the other, so that the moving averages move once per group, in group order (several passes through
+// one layer stacked along the batch axis).
 __global__ __launch_bounds__(256) void bn_finalize_stats_kernel(const float2* __restrict__ partial, float* __restrict__ save_mean,
                                                                 float* __restrict__ save_rstd, float* __restrict__ moving_mean,
                                                                 float* __restrict__ moving_var, BnShape s, float eps,
-                                                                float momentum, int unbiased) {
-    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 6;  // wave-uniform
+                                                                float momentum, int unbiased, int chain_groups) {
+    const int widx = (blockIdx.x * 256 + threadIdx.x) >> 6;  // wave-uniform
     const int lane = threadIdx.x & 63;
-    if (idx >= s.groups * s.c) return;
-    const int grp = idx / s.c, ch = idx - grp * s.c;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int rb = lane; rb < s.rblocks; rb += 64) {
-        const float2 pr = partial[((long)grp * s.rblocks + rb) * s.c + ch];
-        const int r0 = rb * s.rows_per_block;
-        chan_merge(n, mean, m2, (float)(min(s.rows, r0 + s.rows_per_block) - r0), pr.x, pr.y);
-    }
+    if (widx >= (chain_groups ? s.c : s.groups * s.c)) return;
+    const int g0 = chain_groups ? 0 : widx / s.c, g1 = chain_groups ? s.groups : g0 + 1;
+    const int ch = chain_groups ? widx : widx - g0 * s.c;
+    float mm = 0.f, mv = 0.f;
+    if (moving_mean != nullptr && lane == 0) { mm = moving_mean[ch]; mv = moving_var[ch]; }
+    for (int grp = g0; grp < g1; ++grp) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int rb = lane; rb < s.rblocks; rb += 64) {
+            const float2 pr = partial[((long)grp * s.rblocks + rb) * s.c + ch];
+            const int r0 = rb * s.rows_per_block;
+            chan_merge(n, mean, m2, (float)(min(s.rows, r0 + s.rows_per_block) - r0), pr.x, pr.y);
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float nb = __shfl_down(n, off, 64), mb = __shfl_down(mean, off, 64), m2b = __shfl_down(m2, off, 64);
-        chan_merge(n, mean, m2, nb, mb, m2b);
-    }
-    if (lane == 0) {
-        const float var = m2 / n;
-        save_mean[idx] = mean;
-        save_rstd[idx] = 1.0f / sqrtf(var + eps);
-        if (moving_mean != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const float nb = __shfl_down(n, off, 64), mb = __shfl_down(mean, off, 64), m2b = __shfl_down(m2, off, 64);
+            chan_merge(n, mean, m2, nb, mb, m2b);
+        }
+        if (lane == 0) {
+            const float var = m2 / n;
+            save_mean[grp * s.c + ch] = mean;
+            save_rstd[grp * s.c + ch] = 1.0f / sqrtf(var + eps);
             const float v = unbiased ? var * (n / fmaxf(n - 1.f, 1.f)) : var;
-            moving_mean[ch] = moving_mean[ch] * momentum + mean * (1.f - momentum);
-            moving_var[ch] = moving_var[ch] * momentum + v * (1.f - momentum);
+            mm = mm * momentum + mean * (1.f - momentum);
+            mv = mv * momentum + v * (1.f - momentum);
         }
     }
+    if (moving_mean != nullptr && lane == 0) { moving_mean[ch] = mm; moving_var[ch] = mv; }
 }
 
 // y = act((x-mean)*rstd*gamma+beta) + residual.  mean/rstd are per (group, channel); for the
@@ -428,19 +434,13 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     else
         hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(s.rblocks, groups, (c + kChanTile - 1) / kChanTile), dim3(256), 0,
                            st, x, partial, s);
-    if (moving_mean != nullptr && groups > 1) {
-        // several passes through one layer stacked along the batch axis: each group is one pass and
-        // moves the averages in turn, so the groups are finalised one launch after the other
-        BnShape one = s;
-        one.groups = 1;
-        for (int grp = 0; grp < groups; ++grp)
-            hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((c + 3) / 4), dim3(256), 0, st,
-                               partial + (size_t)grp * s.rblocks * c, save_mean + (size_t)grp * c,
-                               save_rstd + (size_t)grp * c, moving_mean, moving_var, one, eps, momentum,
-                               unbiased_moving_var);
-    } else {
-        hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((groups * c + 3) / 4), dim3(256), 0, st, partial, save_mean,
-                           save_rstd, moving_mean, moving_var, s, eps, momentum, unbiased_moving_var);
+    {
+        // several passes through one layer stacked along the batch axis: each group is one pass and moves
+        // the averages in turn, inside one launch
+        const int chain = (moving_mean != nullptr && groups > 1) ? 1 : 0;
+        const int waves = chain ? c : groups * c;
+        hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, partial, save_mean,
+                           save_rstd, moving_mean, moving_var, s, eps, momentum, unbiased_moving_var, chain);
     }
     const long total = (long)groups * rows * c;
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for((c & 3) ? total : total / 4)), dim3(256), 0, st, x, gamma,
