@@ -799,7 +799,12 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
     // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4
     const bool split_ok = pl.va == 4 && pl.vb == 4 && a.a_bytes != 0 && a.b_bytes != 0 && !exact_f32();
-    if (split_ok && pl.cfg < 3) pl.cfg += kFirstSplitCfg;
+    if (split_ok && pl.cfg < 3) {
+        // the split kernel converts every staged value, so it wants the largest tile that still leaves
+        // enough blocks: 128x128 from 1024 rows on (the tuned DCGAN / CycleGAN plans agree)
+        if (N >= 128 && M >= 1024) pl.cfg = 0;
+        pl.cfg += kFirstSplitCfg;
+    }
     int pinned_splits = 0;
     {
         std::lock_guard<std::mutex> lock(g_plan_mu);
@@ -818,7 +823,8 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     const long blocks = (long)pl.mt * pl.nt * (mode == MODE_TPROP ? a.ncls : 1);
     int splits = 1;
     // one co-resident wave of blocks: the fp32 kernel fits 3 blocks per CU, the split kernel 2
-    const long target = pl.cfg >= kFirstSplitCfg ? 512 : 768;
+    // (LDS and registers allow 2 / 3 / 5 blocks per CU for its 128x128 / 128x64 / 64x64 tiles)
+    const long target = pl.cfg == 4 ? 512 : (pl.cfg == 5 ? 768 : (pl.cfg == 6 ? 1280 : 768));
     if (blocks < target) {
         splits = (int)(target / blocks);
         const int max_by_k = nkt / 8 > 0 ? nkt / 8 : 1;  // keep >= 8 k-slices (128 deep) per split
