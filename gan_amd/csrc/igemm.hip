@@ -827,7 +827,7 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
     const long target = pl.cfg == 4 ? 512 : (pl.cfg == 5 ? 768 : (pl.cfg == 6 ? 1280 : 768));
     if (blocks < target) {
         splits = (int)(target / blocks);
-        const int max_by_k = nkt / 8 > 0 ? nkt / 8 : 1;  // keep >= 8 k-slices (128 deep) per split
+        const int max_by_k = nkt / 12 > 0 ? nkt / 12 : 1;  // keep >= 12 k-slices per split: shorter loops are all prologue
         if (splits > max_by_k) splits = max_by_k;
         // the slabs are written once and read once: keep them to a few tens of MB
         const long max_by_bytes = (48L << 20) / (pl.out_elems * (long)sizeof(float) + 1);

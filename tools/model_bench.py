@@ -48,8 +48,9 @@ def main():
     ap.add_argument("--model", default="all")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
     args = ap.parse_args()
-    autotune.enable(True)
+    autotune.enable(not args.no_autotune)
     rng = np.random.default_rng(0)
     P = build_parser()
     if args.model in ("mnist", "all"):
