@@ -275,6 +275,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (ty == 0 && ch < c) partial[(long)blockIdx.x * c + ch] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
+// c <= 4 (the bias gradient of an image-producing layer): a thread takes whole rows, so every lane works
+// and a wave reads a contiguous run of rows.
+template <int C>
+__global__ __launch_bounds__(256) void colsum_partial_thin_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                                  long rows, long rows_per_block) {
+    __shared__ float red[C][256];
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) s[k] = 0.f;
+    for (long r = r0 + threadIdx.x; r < r1; r += 256) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) s[k] += x[r * C + k];
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int j = 0; j < 256; ++j) t += red[threadIdx.x][j];
+        partial[(long)blockIdx.x * C + threadIdx.x] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int c,
                                                            int rblocks, int accumulate) {
     const int ch = (blockIdx.x * 256 + threadIdx.x) >> 6;  // one wave per channel
@@ -293,6 +318,9 @@ static void colsum_plan(long rows, int c, int* rblocks, long* rows_per_block) {
     if (colsum_vec4(c)) {
         const int row_lanes = 256 / (c / 4);
         rb = (rows + row_lanes * 4 - 1) / (row_lanes * 4);
+        if (rb > 1024) rb = 1024;
+    } else if (c <= 3) {
+        rb = (rows + 1023) / 1024;      // four rows per thread
         if (rb > 1024) rb = 1024;
     } else {
         const int ctiles = (c + 63) / 64;
@@ -323,6 +351,12 @@ int colsum(const float* x, float* out, long rows, int c, int accumulate, void* w
                   ws_bytes);
     if (colsum_vec4(c))
         hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(rb), dim3(256), 0, st, x, static_cast<float*>(ws), rows, c, rpb);
+    else if (c == 3)
+        hipLaunchKernelGGL(colsum_partial_thin_kernel<3>, dim3(rb), dim3(256), 0, st, x, static_cast<float*>(ws), rows, rpb);
+    else if (c == 2)
+        hipLaunchKernelGGL(colsum_partial_thin_kernel<2>, dim3(rb), dim3(256), 0, st, x, static_cast<float*>(ws), rows, rpb);
+    else if (c == 1)
+        hipLaunchKernelGGL(colsum_partial_thin_kernel<1>, dim3(rb), dim3(256), 0, st, x, static_cast<float*>(ws), rows, rpb);
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(rb, (c + 63) / 64), dim3(256), 0, st, x, static_cast<float*>(ws), rows,
                            c, rpb);
