@@ -355,6 +355,21 @@ class Text2Image(object):
         z_noise = np.asarray([[rng.uniform(-1, 1) for _ in range(self.z_dim)] for _ in range(bs)], np.float32)
         return real_images, wrong_images, captions, z_noise, image_files
 
+    def save_for_vis(self, real_images, generated_images, image_files):
+        """text2image.py:343-358: the batch's real images (named after their files) and generated images as
+        jpg files under <sample_dir>/text2image_<textEncoder> (scipy.misc.imsave's stretch to 0..255)."""
+        from PIL import Image
+        from .misc import bytescale
+        sample_dir = os.path.join(self.sample_dir, 'text2image_' + self.textEncoder)
+        if not os.path.exists(sample_dir):
+            os.makedirs(sample_dir)
+        real_images, generated_images = np.asarray(real_images), np.asarray(generated_images)
+        for i in range(0, real_images.shape[0]):
+            Image.fromarray(bytescale(real_images[i])).save(
+                os.path.join(sample_dir, '{}_{}.jpg'.format(i, image_files[i].split('/')[-1])))
+            Image.fromarray(bytescale(generated_images[i])).save(os.path.join(sample_dir, 'fake_image_{}.jpg'.format(i)))
+        return sample_dir
+
     def train_from_files(self, data_dir=None, max_iters=None, seed=None):
         """The training loop of text2image.py:224-285 over the flowers files."""
         dev = self.store.device
@@ -367,13 +382,15 @@ class Text2Image(object):
         for i in range(self.nEpochs):
             batch_no = 0
             while batch_no * self.batch_size < loaded['data_length']:
-                real, wrong, cap, z, _ = self.get_training_batch(batch_no, loaded, data_dir, rng)
+                real, wrong, cap, z, image_files = self.get_training_batch(batch_no, loaded, data_dir, rng)
                 out = self.train_iteration(*[torch.from_numpy(a).to(dev) for a in (real, wrong, cap, z)])
                 d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
                 print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
                     i, batch_no, n_batch, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
                 batch_no += 1
                 if (batch_no % self.save_every_batch) == 0:
+                    print("Saving Images, Model")
+                    self.save_for_vis(real, out['generator'].cpu().numpy(), image_files)
                     self.save(self.checkpoint_dir, batch_no)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:

@@ -112,9 +112,11 @@ def test_text2image_trains_from_the_flowers_files(tmp_path):
         np.save(str(tmp_path / "flowers_caption_icml" / "class_00001" / (name + ".npy")),
                 rng.standard_normal((10, 1024)).astype(np.float32))
     o = parse(("--model Text2Image --dataset flowers --input_height 64 --textEncoder DSSJE --batch_size 4 --gf_dim 4 "
-               "--df_dim 4 --t_dim 8 --caption_vector_length 12 --z_dim 10 --nEpochs 1").split()
+               "--df_dim 4 --t_dim 8 --caption_vector_length 12 --z_dim 10 --nEpochs 1 --save_every_batch 2").split()
               + ["--data_dir", str(tmp_path), "--checkpoint_dir", str(tmp_path / "ck"), "--sample_dir", str(tmp_path / "smp")])
     out = main(o)           # 9 training images / batch 4 -> 3 batches
     assert all(np.isfinite(float(out[k])) for k in ('d_loss1', 'd_loss2', 'd_loss3', 'g_loss_1', 'g_loss_2'))
     assert out['generator'].shape == (4, 64, 64, 3)
     assert (tmp_path / "ck" / "Text2Image_flowers_4_64").exists()       # the end-of-epoch checkpoint
+    vis = tmp_path / "smp" / "Text2Image" / "flowers" / "text2image_DSSJE"   # save_for_vis after batch 2
+    assert len(list(vis.glob("fake_image_*.jpg"))) == 4 and len(list(vis.glob("*_image_*.jpg"))) >= 8
