@@ -234,9 +234,11 @@ class CycleGAN(object):
         random crop to fine_size, random flip) or in-memory [N, s, s, c] float arrays in [-1, 1].
         Both are shuffled every epoch and paired by position; a batch is real_A | real_B on the
         channel axis.  Every `sample_every` iterations the translations of the current batch go to
-        opts.sample_dir (sample_model, :216-236; 0 disables it)."""
+        opts.sample_dir (sample_model, :216-236; 0 disables it).  Batches are prepared ahead of the GPU on a
+        background thread, in loop order (the crop / flip draws keep their sequence)."""
         from glob import glob
         from .misc import load_data, save_images
+        from .prefetch import BatchPrefetcher, to_device
         opts = self.options
         dev = self.store.device
         rng = np.random.RandomState(seed)
@@ -257,15 +259,18 @@ class CycleGAN(object):
         for epoch in range(opts.nEpochs):
             ia, ib = rng.permutation(len(dataA)), rng.permutation(len(dataB))
             batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // self.batch_size
-            for idx in range(0, batch_idxs):
+
+            def make(idx, ia=ia, ib=ib):
                 sl = slice(idx * self.batch_size, (idx + 1) * self.batch_size)
                 if from_files:
-                    batch = np.array([load_data((dataA[a], dataB[b]), flip=getattr(opts, 'flip', True),
-                                                load_size=getattr(opts, 'load_size', 286), fine_size=self.image_size, rng=rng)
-                                      for a, b in zip(ia[sl], ib[sl])]).astype(np.float32)
-                else:
-                    batch = np.concatenate([np.asarray(dataA)[ia[sl]], np.asarray(dataB)[ib[sl]]], axis=3).astype(np.float32)
-                real = torch.from_numpy(batch).to(dev)
+                    return np.array([load_data((dataA[a], dataB[b]), flip=getattr(opts, 'flip', True),
+                                               load_size=getattr(opts, 'load_size', 286), fine_size=self.image_size, rng=rng)
+                                     for a, b in zip(ia[sl], ib[sl])]).astype(np.float32)
+                return np.concatenate([np.asarray(dataA)[ia[sl]], np.asarray(dataB)[ib[sl]]], axis=3).astype(np.float32)
+
+            feed = BatchPrefetcher(make, range(0, batch_idxs), depth=int(getattr(opts, 'prefetch_batches', 4)))
+            for idx, host_batch in feed:
+                real = to_device(host_batch, dev)
                 out = self.train_iteration(real)
                 counter += 1
                 print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
@@ -280,6 +285,7 @@ class CycleGAN(object):
                     self.save(opts.checkpoint_dir, counter)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
+                    feed.close()
                     return out
         return out
 

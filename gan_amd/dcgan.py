@@ -335,53 +335,49 @@ class DCGAN(object):
         G update 1 | G Adam + G update 2 | G Adam) and the all-reduces of the flat gradient arenas
         are issued between them on the same stream.  Returns run(images, z, y=None) -> the dict
         train_iteration returns."""
-        from .graph import CapturedIteration, SegmentedIteration, model_state_restore, model_state_snapshot
-        optims = [self.d_optim, self.g_optim]
-        snap = lambda: model_state_snapshot(self.store, optims)
-        rest = lambda s: model_state_restore(self.store, optims, s)
-        static = [images.clone(), z.clone(), None if y is None else y.clone()]
-        ws, pg = self.world_size, self.process_group
-
-        def refresh(im, zz, yy):
-            for dst, src in zip(static, (im, zz, yy)):
-                if dst is not None and src is not dst:
-                    dst.copy_(src, non_blocking=True)
-
-        if segmented is None:
-            segmented = ws > 1 or pg is not None
-        if not segmented:
-            whole = CapturedIteration(lambda a, b, c: self.train_iteration(a, b, c), static, snap, rest, share_inputs=True)
-
-            def run(im, zz, yy=None):
-                refresh(im, zz, yy)
-                return whole(*static)
-            return run
-
-        chain = SegmentedIteration(lambda a, b, c: self.train_iteration(a, b, c), static, snap, rest)
-
-        def run(im, zz, yy=None):
-            refresh(im, zz, yy)
-            return chain()
-        return run
+        from .graph import iteration_runner
+        run = iteration_runner(self.store, [self.d_optim, self.g_optim], lambda a, b, c: self.train_iteration(a, b, c),
+                               [images, z, y], self.world_size, self.process_group, segmented)
+        return lambda im, zz, yy=None: run(im, zz, yy)
 
     # ------------------------------------------------------------------------------------ train loop
-    def _load_files(self, files):
-        """dcgan.py:210-221: centre-crop / resize / scale a list of image files to one NHWC batch."""
-        from .misc import get_image
-        batch = [get_image(f, input_height=self.input_height, input_width=self.input_width,
-                           resize_height=self.output_height, resize_width=self.output_width, crop=self.crop,
-                           grayscale=self.grayscale) for f in files]
-        arr = np.array(batch).astype(np.float32)
+    def _load_files_u8(self, files, pool_map=None):
+        """dcgan.py:210-221 up to the scaling: centre-crop / resize a list of image files to one uint8 NHWC
+        batch.  `pool_map(fn, items)` (order-keeping) spreads the files over worker threads."""
+        from .misc import get_image_u8
+        one = lambda f: get_image_u8(f, input_height=self.input_height, input_width=self.input_width,
+                                     resize_height=self.output_height, resize_width=self.output_width, crop=self.crop,
+                                     grayscale=self.grayscale)
+        arr = np.array(pool_map(one, files) if pool_map is not None else [one(f) for f in files], dtype=np.uint8)
         return arr[:, :, :, None] if self.grayscale else arr
+
+    @staticmethod
+    def _scale_u8(images):
+        """uint8 batch -> the network's input range, with the arithmetic of misc.py:90 followed by the
+        float32 cast of dcgan.py:221 (`x / 127.5 - 1.` in float64): bit-identical on host and GPU."""
+        if torch.is_tensor(images):
+            return (images.double() / 127.5 - 1.0).float()
+        return (np.asarray(images) / 127.5 - 1.).astype(np.float32)
+
+    def _load_files(self, files, pool_map=None):
+        """dcgan.py:210-221: a list of image files as one float32 NHWC batch in [-1, 1]."""
+        return self._scale_u8(self._load_files_u8(files, pool_map))
 
     def train(self, data_X=None, data_y=None, max_iters=None, data_files=None, sample_every=100):
         """dcgan.py:151-320.  Data comes from in-memory arrays ([N,H,W,C] in the network's input
         range, plus one-hot labels for the conditional model: MNIST via load_mnist), or from image
         files: `data_files`, else ./data/<dataset>/<input_fname_pattern> as in the reference
         (:200-201).  Every `sample_every` iterations a grid of sampler outputs is written to
-        opts.sample_dir (:287-317; 0 disables it)."""
+        opts.sample_dir (:287-317; 0 disables it).
+
+        Batches are prepared ahead of the GPU on a background thread (prefetch.BatchPrefetcher), and the
+        loop body is replayed as HIP graphs (iteration_runner) unless opts.use_graph is false; the
+        logging evaluations, the sampler and the checkpoints run eagerly between replays.  Image files
+        travel as uint8 and are scaled on the GPU; the first epoch also leaves them in GPU memory
+        (opts.dataset_cache_gb, default 32: CelebA at 64x64 is 2.4 GB), so that later epochs decode nothing."""
         from glob import glob
         from .misc import save_images
+        from .prefetch import BatchPrefetcher, to_device
         opts = self.opts
         if data_X is None and data_files is None:
             data_X, data_y = self.data_X, self.data_y
@@ -406,21 +402,66 @@ class DCGAN(object):
         else:
             print(" [!] Load failed...")
         iters = 0
+        use_graph = bool(getattr(opts, 'use_graph', True))
+        run = None
+        cache, cached = None, [0]          # uint8 images of the file data set in GPU memory; batches stored so far
         for epoch in range(opts.nEpochs):
             n_items = len(data_X) if data_X is not None else len(data_files)
             batch_idxs = int(min(n_items, opts.train_size)) // opts.batch_size
-            for idx in range(0, batch_idxs):
-                sl = slice(idx * opts.batch_size, (idx + 1) * opts.batch_size)
-                host_batch = (np.asarray(data_X[sl], dtype=np.float32) if data_X is not None
-                              else self._load_files(data_files[sl]))
-                batch_images = torch.from_numpy(host_batch).to(dev)
-                batch_labels = None
-                if self.y_dim:
-                    batch_labels = torch.from_numpy(np.asarray(data_y[sl], dtype=np.float32)).to(dev)
+
+            from_files = data_X is None
+            if from_files and cache is None and epoch == 0:
+                nbytes = batch_idxs * opts.batch_size * self.output_height * self.output_width * self.c_dim
+                if 0 < nbytes <= float(getattr(opts, 'dataset_cache_gb', 32)) * 2 ** 30:
+                    cache = torch.empty((batch_idxs * opts.batch_size, self.output_height, self.output_width, self.c_dim),
+                                        dtype=torch.uint8, device=dev)
+
+            def device_batches():
+                """(idx, images, labels) on the GPU: from the resident uint8 copy once an epoch has filled
+                it, else from the input pipeline."""
+                if from_files and cache is not None and cached[0] >= batch_idxs:
+                    for idx in range(0, batch_idxs):
+                        sl = slice(idx * opts.batch_size, (idx + 1) * opts.batch_size)
+                        labels = None
+                        if self.y_dim and data_y is not None:
+                            labels = torch.from_numpy(np.asarray(data_y[sl], dtype=np.float32)).to(dev)
+                        yield idx, self._scale_u8(cache[sl]), labels
+                    return
+
+                def make(idx):
+                    sl = slice(idx * opts.batch_size, (idx + 1) * opts.batch_size)
+                    images = (np.asarray(data_X[sl], dtype=np.float32) if not from_files
+                              else self._load_files_u8(data_files[sl], feed.pool_map))
+                    labels = np.asarray(data_y[sl], dtype=np.float32) if (self.y_dim and data_y is not None) else None
+                    return images, labels
+
+                feed = BatchPrefetcher(make, range(0, batch_idxs), depth=int(getattr(opts, 'prefetch_batches', 4)),
+                                       workers=int(getattr(opts, 'num_preprocess_threads', 4)))
+                try:
+                    for idx, host_batch in feed:
+                        images, labels = to_device(host_batch, dev)
+                        if from_files:
+                            if cache is not None and cached[0] == idx:
+                                cache[idx * opts.batch_size:(idx + 1) * opts.batch_size].copy_(images)
+                                cached[0] = idx + 1
+                            images = self._scale_u8(images)
+                        yield idx, images, labels
+                finally:
+                    feed.close()
+
+            for idx, batch_images, batch_labels in device_batches():
                 batch_z = torch.from_numpy(
                     rng.uniform(-1, 1, [opts.batch_size, self.z_dim]).astype(np.float32)).to(dev)
                 log = (idx % self.print_every == 0)
-                out = self.train_iteration(batch_images, batch_z, batch_labels, log_evals=log)
+                if use_graph:
+                    if run is None:
+                        run = self.iteration_runner(batch_images, batch_z, batch_labels)
+                    out = dict(run(batch_images, batch_z, batch_labels))
+                    if log:
+                        f, r, g = self.eval_losses(batch_images, batch_z, batch_labels)
+                        out.update(errD_fake=f, errD_real=r, errG=g)
+                else:
+                    out = self.train_iteration(batch_images, batch_z, batch_labels, log_evals=log)
                 self.counter += 1
                 if log:
                     print("Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f"
@@ -438,7 +479,7 @@ class DCGAN(object):
                     self.save(opts.checkpoint_dir, self.counter)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
-                    return
+                    return                  # (closing the generator stops the input pipeline)
 
     # ------------------------------------------------------------------------------------ data
     def load_mnist(self):

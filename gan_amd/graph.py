@@ -9,6 +9,8 @@ The Adam step count lives in device memory, so replays advance the bias correcti
 """
 import torch
 
+from .prefetch import capture_lock
+
 
 class CapturedIteration(object):
     """Capture `fn(*inputs)`; inputs are copied into static buffers before every replay.
@@ -34,8 +36,9 @@ class CapturedIteration(object):
             restore(saved)
         saved = snapshot() if snapshot is not None else None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = fn(*self.static_inputs)
+        with capture_lock:                      # no page-locking by the input pipeline's thread meanwhile
+            with torch.cuda.graph(self.graph):
+                self.outputs = fn(*self.static_inputs)
         torch.cuda.synchronize()
         if restore is not None:
             restore(saved)                      # capture does not execute, but keep the contract explicit
@@ -79,18 +82,19 @@ class SegmentedIteration(object):
         self._pool = torch.cuda.graph_pool_handle()
         self._capturing = False
         SegmentedIteration.active = self
-        try:
-            self._open()
-            self.outputs = fn(*self.static_inputs)
-            self._close(None)
-        finally:
-            SegmentedIteration.active = None
-            if self._capturing:             # fn raised: leave the stream out of capture mode
-                try:
-                    self._graph.capture_end()
-                finally:
-                    self._ctx.__exit__(None, None, None)
-                    self._capturing = False
+        with capture_lock:                      # no page-locking by the input pipeline's thread meanwhile
+            try:
+                self._open()
+                self.outputs = fn(*self.static_inputs)
+                self._close(None)
+            finally:
+                SegmentedIteration.active = None
+                if self._capturing:         # fn raised: leave the stream out of capture mode
+                    try:
+                        self._graph.capture_end()
+                    finally:
+                        self._ctx.__exit__(None, None, None)
+                        self._capturing = False
         torch.cuda.synchronize()
         if restore is not None:
             restore(saved)
@@ -146,3 +150,33 @@ def model_state_restore(store, optims, snap):
         g.v.copy_(v)
     for o, s in zip(optims, snap['steps']):
         o.step_dev.copy_(s)
+
+
+def iteration_runner(store, optims, fn, example_inputs, world_size=1, process_group=None, segmented=None):
+    """`fn(*inputs)` (one training iteration of a model whose variables live in `store` and are stepped by
+    `optims`) as replayable HIP graphs over static copies of `example_inputs` (None members stay None).
+
+    One GPU: one graph.  Data parallel (or `segmented`): a chain of graphs cut at the gradient exchanges,
+    which run between them on the same stream.  Returns run(*inputs) -> what fn returns; the tensors in
+    it are static and overwritten by the next replay."""
+    snap = lambda: model_state_snapshot(store, optims)
+    rest = lambda s: model_state_restore(store, optims, s)
+    static = [None if t is None else t.clone() for t in example_inputs]
+    if segmented is None:
+        segmented = world_size > 1 or process_group is not None
+    if segmented:
+        replay = SegmentedIteration(fn, static, snap, rest)
+    else:
+        whole = CapturedIteration(fn, static, snap, rest, share_inputs=True)
+        replay = lambda: whole(*static)
+
+    def run(*inputs):
+        if len(inputs) > len(static):
+            raise ValueError("iteration runner captured with %d inputs, called with %d" % (len(static), len(inputs)))
+        for dst, src in zip(static, inputs):
+            if dst is not None and src is not dst:
+                if src is None:
+                    raise ValueError("iteration runner: an input that was a tensor at capture time is None now")
+                dst.copy_(src, non_blocking=True)
+        return replay()
+    return run

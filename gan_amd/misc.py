@@ -80,19 +80,28 @@ def center_crop(x, crop_h, crop_w=None, resize_h=64, resize_w=64):
     return imresize(x[j:j + crop_h, i:i + crop_w], [resize_h, resize_w])
 
 
+def transform_u8(image, input_height, input_width, resize_height=64, resize_width=64, crop=True):
+    """The uint8 image that misc.py:82-90 then scales: centre crop (or none) and resize."""
+    if crop:
+        return center_crop(image, input_height, input_width, resize_height, resize_width)
+    return imresize(image, [resize_height, resize_width])
+
+
 def transform(image, input_height, input_width, resize_height=64, resize_width=64, crop=True):
     """misc.py:82-90: to [-1, 1]"""
-    if crop:
-        cropped_image = center_crop(image, input_height, input_width, resize_height, resize_width)
-    else:
-        cropped_image = imresize(image, [resize_height, resize_width])
-    return np.array(cropped_image) / 127.5 - 1.
+    return np.array(transform_u8(image, input_height, input_width, resize_height, resize_width, crop)) / 127.5 - 1.
 
 
 def get_image(image_path, input_height, input_width, resize_height=64, resize_width=64, crop=True, grayscale=False):
     """misc.py:28-33"""
     image = imread(image_path, grayscale)
     return transform(image, input_height, input_width, resize_height, resize_width, crop)
+
+
+def get_image_u8(image_path, input_height, input_width, resize_height=64, resize_width=64, crop=True, grayscale=False):
+    """get_image before its last step: get_image(...) == get_image_u8(...) / 127.5 - 1. (in float64).  A quarter
+    of the bytes to keep or move; the scaling can then run where the batch is consumed."""
+    return transform_u8(imread(image_path, grayscale), input_height, input_width, resize_height, resize_width, crop)
 
 
 def inverse_transform(images):

@@ -66,6 +66,9 @@ class Text2Image(object):
         self.resume_model = getattr(options, 'resume_model', None)
         self.data_dir = getattr(options, 'data_dir', 'data')
         self.save_every_batch = getattr(options, 'save_every_batch', 50)
+        self.use_graph = bool(getattr(options, 'use_graph', True))
+        self.prefetch_batches = int(getattr(options, 'prefetch_batches', 4))
+        self._runner = None
         self.world_size, self.process_group = world_size, process_group
         self.stack_d_passes = True      # D update: the three D applications as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
@@ -264,23 +267,44 @@ class Text2Image(object):
         g2, gen = self.g_update(real_caption, z)
         return {'d_loss1': d1, 'd_loss2': d2, 'd_loss3': d3, 'g_loss_1': g1, 'g_loss_2': g2, 'generator': gen}
 
+    def iteration_runner(self, real_image, wrong_image, real_caption, z, segmented=None):
+        """train_iteration as replayable HIP graphs over static input buffers (one graph on one GPU, a
+        chain cut at the gradient exchanges when data parallel).  Returns run(real, wrong, caption, z)."""
+        from .graph import iteration_runner
+        return iteration_runner(self.store, [self.d_optim, self.g_optim],
+                                lambda a, b, c, d: self.train_iteration(a, b, c, d),
+                                [real_image, wrong_image, real_caption, z], self.world_size, self.process_group, segmented)
+
+    def _step(self, batch):
+        """One iteration on a device batch (real, wrong, captions, z): graph replay unless use_graph is off."""
+        if not self.use_graph:
+            return self.train_iteration(*batch)
+        if self._runner is None:
+            self._runner = self.iteration_runner(*batch)
+        return self._runner(*batch)
+
     def train(self, images, captions, max_iters=None, seed=0):
         """text2image.py:224-285 for in-memory data: images [N,s,s,3] floats in [0,1], captions
         [N, caption_vector_length].  The wrong image of a sample is a random other image
-        (get_training_batch, :389-397)."""
+        (get_training_batch, :389-397).  Batches are prepared ahead of the GPU on a background thread."""
+        from .prefetch import BatchPrefetcher, to_device
         dev = self.store.device
         rng = np.random.RandomState(seed)
         n = len(images)
         iters = 0
+
+        def make(batch_no):
+            sl = slice(batch_no * self.batch_size, (batch_no + 1) * self.batch_size)
+            return (np.asarray(images[sl], dtype=np.float32),
+                    np.asarray(images[rng.randint(0, n, self.batch_size)], dtype=np.float32),
+                    np.asarray(captions[sl], dtype=np.float32),
+                    rng.uniform(-1, 1, [self.batch_size, self.z_dim]).astype(np.float32))
+
         for i in range(self.nEpochs):
             batch_no = 0
-            while (batch_no + 1) * self.batch_size <= n:
-                sl = slice(batch_no * self.batch_size, (batch_no + 1) * self.batch_size)
-                real = torch.from_numpy(np.asarray(images[sl], dtype=np.float32)).to(dev)
-                wrong = torch.from_numpy(np.asarray(images[rng.randint(0, n, self.batch_size)], dtype=np.float32)).to(dev)
-                cap = torch.from_numpy(np.asarray(captions[sl], dtype=np.float32)).to(dev)
-                z = torch.from_numpy(rng.uniform(-1, 1, [self.batch_size, self.z_dim]).astype(np.float32)).to(dev)
-                out = self.train_iteration(real, wrong, cap, z)
+            feed = BatchPrefetcher(make, range(n // self.batch_size), depth=self.prefetch_batches)
+            for _, host_batch in feed:
+                out = self._step(to_device(host_batch, dev))
                 d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
                 print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
                     i, batch_no, n // self.batch_size, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
@@ -289,6 +313,7 @@ class Text2Image(object):
                     self.save(self.checkpoint_dir, batch_no)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
+                    feed.close()
                     return
             if i % 5 == 0:
                 self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))
@@ -371,7 +396,8 @@ class Text2Image(object):
         return sample_dir
 
     def train_from_files(self, data_dir=None, max_iters=None, seed=None):
-        """The training loop of text2image.py:224-285 over the flowers files."""
+        """The training loop of text2image.py:224-285 over the flowers files (batches read ahead of the GPU)."""
+        from .prefetch import BatchPrefetcher, to_device
         dev = self.store.device
         rng = random.Random(seed)
         loaded = self.load_training_data(data_dir, self.dataset, seed)
@@ -379,21 +405,26 @@ class Text2Image(object):
             raise RuntimeError("no flowers training images found under %s" % (data_dir or self.data_dir))
         n_batch = loaded['data_length'] // self.batch_size
         iters, out = 0, None
+        n_feeds = (loaded['data_length'] + self.batch_size - 1) // self.batch_size     # the last one wraps around
         for i in range(self.nEpochs):
             batch_no = 0
-            while batch_no * self.batch_size < loaded['data_length']:
-                real, wrong, cap, z, image_files = self.get_training_batch(batch_no, loaded, data_dir, rng)
-                out = self.train_iteration(*[torch.from_numpy(a).to(dev) for a in (real, wrong, cap, z)])
+            # one producer thread draws the random numbers of the batches in the order of the inline loop
+            feed = BatchPrefetcher(lambda b: self.get_training_batch(b, loaded, data_dir, rng), range(n_feeds),
+                                   depth=self.prefetch_batches)
+            for _, host_batch in feed:
+                real, wrong, cap, z, image_files = host_batch
+                out = self._step(to_device((real, wrong, cap, z), dev))
                 d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
                 print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
                     i, batch_no, n_batch, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
                 batch_no += 1
                 if (batch_no % self.save_every_batch) == 0:
                     print("Saving Images, Model")
-                    self.save_for_vis(real, out['generator'].cpu().numpy(), image_files)
+                    self.save_for_vis(real.numpy(), out['generator'].cpu().numpy(), image_files)
                     self.save(self.checkpoint_dir, batch_no)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
+                    feed.close()
                     return out
             if i % 5 == 0:
                 self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))

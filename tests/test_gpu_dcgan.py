@@ -295,3 +295,63 @@ def test_default_and_exact_f32_contraction_arithmetic_train_alike():
     la, lb = np.array(la), np.array(lb)
     assert np.abs(la[0] - lb[0]).max() <= 2e-5 * max(1.0, np.abs(lb[0]).max()), (la[0], lb[0])
     assert np.abs(la - lb).max() <= 2e-2, np.abs(la - lb).max(axis=0)
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_train_loop_with_graph_replay_and_prefetch_equals_eager_loop(cond, tmp_path, capsys):
+    """DCGAN.train replays the iteration as a HIP graph and takes its batches from the background input
+    pipeline; with use_graph off it issues every launch eagerly.  Same data, same seeds: the same log lines
+    and bit-identical variables, Adam step counts included."""
+    kw = dict(y_dim=4, c_dim=1, output_height=28, output_width=28, input_height=28, input_width=28, dataset='mnist') if cond else {}
+    rng = np.random.default_rng(5)
+    n = 5 * 8
+    data_X = rng.uniform(0 if cond else -1, 1, (n, 28 if cond else 16, 28 if cond else 16, 1 if cond else 3)).astype(np.float32)
+    data_y = np.eye(4, dtype=np.float32)[rng.integers(0, 4, n)] if cond else None
+    logs, models = [], []
+    for use_graph in (True, False):
+        opts = make_opts(checkpoint_dir=str(tmp_path / ("ck%d" % use_graph)), sample_dir=str(tmp_path / "smp"),
+                         use_graph=use_graph, print_every=2, **kw)
+        _, gpu, _ = build_pair(opts, seed=13)
+        capsys.readouterr()
+        gpu.train(data_X=data_X, data_y=data_y, sample_every=3)
+        logs.append([l.split("time:")[0] + l.split(",", 1)[1] for l in capsys.readouterr().out.splitlines() if l.startswith("Epoch")])
+        models.append(gpu)
+    assert len(logs[0]) == 3 and logs[0] == logs[1]
+    a, b = models
+    assert a.counter == b.counter == 6            # the reference starts its counter at 1 (dcgan.py:189)
+    assert a.d_optim.steps_taken == b.d_optim.steps_taken == 5 and a.g_optim.steps_taken == b.g_optim.steps_taken == 10
+    for name, v in a.store.vars.items():
+        assert torch.equal(v.data, b.store.vars[name].data), name
+    assert [p.name for p in (tmp_path / "smp").glob("train_00_*.png")] == ["train_00_0002.png"]     # counter 4
+
+
+def test_train_from_image_files_with_resident_uint8_copy_equals_decoding_every_epoch(tmp_path, capsys):
+    """Image files: epoch 1 decodes them on the input pipeline's threads, ships uint8 and scales on the GPU;
+    epoch 2 reads the uint8 copy left in GPU memory.  Against the loop that decodes every batch inline,
+    scales on the host and launches eagerly: same log, bit-identical variables."""
+    from PIL import Image
+    from gan_amd.misc import get_image
+    rng = np.random.default_rng(8)
+    files = []
+    for i in range(19):                                  # 2 batches of 8 per epoch, 3 files left over
+        f = tmp_path / ("img%03d.png" % i)
+        Image.fromarray(rng.integers(0, 256, (30, 26, 3), dtype=np.uint8)).save(f)
+        files.append(str(f))
+    logs, models = [], []
+    for fast in (True, False):
+        opts = make_opts(checkpoint_dir=str(tmp_path / ("ck%d" % fast)), sample_dir=str(tmp_path / "smp"), nEpochs=2,
+                         input_height=20, input_width=20, use_graph=fast, dataset_cache_gb=32 if fast else 0)
+        _, gpu, _ = build_pair(opts, seed=17)
+        if not fast:                                     # the reference's inline float path, batch by batch
+            gpu._load_files_u8 = None
+            gpu._scale_u8 = lambda t: t
+            batches = {tuple(files[i:i + 8]): np.array([get_image(f, 20, 20, 16, 16, True, False) for f in files[i:i + 8]]
+                                                       ).astype(np.float32) for i in (0, 8)}
+            gpu._load_files_u8 = lambda fs, pool_map=None: batches[tuple(fs)]
+        capsys.readouterr()
+        gpu.train(data_files=files, sample_every=0)
+        logs.append([l.split("time:")[0] + l.split(",", 1)[1] for l in capsys.readouterr().out.splitlines() if l.startswith("Epoch")])
+        models.append(gpu)
+    assert len(logs[0]) == 4 and logs[0] == logs[1]
+    for name, v in models[0].store.vars.items():
+        assert torch.equal(v.data, models[1].store.vars[name].data), name

@@ -44,6 +44,16 @@ def test_transform_center_crop_and_inverse(tmp_path):
     assert g.shape == (8, 8, 3) and -1.0 <= g.min() and g.max() <= 1.0
     gg = get_image(path, 20, 10, resize_height=8, resize_width=8, crop=False, grayscale=True)
     assert gg.shape == (8, 8)
+    # the uint8 form that travels to the GPU: scaling it there (float64, then the float32 cast) is get_image
+    import torch
+    from gan_amd.dcgan import DCGAN
+    from gan_amd.misc import get_image_u8
+    for kw in (dict(crop=True), dict(crop=False, grayscale=True)):
+        u8 = get_image_u8(path, 20, 10, resize_height=8, resize_width=8, **kw)
+        want = get_image(path, 20, 10, resize_height=8, resize_width=8, **kw).astype(np.float32)
+        assert u8.dtype == np.uint8
+        np.testing.assert_array_equal(DCGAN._scale_u8(u8), want)
+        np.testing.assert_array_equal(DCGAN._scale_u8(torch.from_numpy(u8.copy())).numpy(), want)
 
 
 def test_save_images_writes_the_grid(tmp_path):
