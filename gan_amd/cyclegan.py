@@ -204,7 +204,7 @@ class CycleGAN(object):
         real_A, real_B = self.split(real_data)
         # Forward G network
         fake_A, fake_B = self.forward_fakes(real_data, keep=True)
-        [fake_A, fake_B] = self.pool([fake_A, fake_B])
+        fake_A, fake_B = self._pooled(fake_A, fake_B)
         out = {}
         # Update D network
         r, f = self.d_update('B', real_B, fake_B)
@@ -218,6 +218,36 @@ class CycleGAN(object):
         out['g_b2a_gan'], out['g_b2a_cyc_a'], out['g_b2a_cyc_b'] = self.g_update('b2a', real_data)
         self._kept = {}
         return out
+
+    def _pooled(self, fake_A, fake_B):
+        """[fake_A, fake_B] = self.pool([fake_A, fake_B]) (cyclegan.py:162).  The pool's coin toss is host
+        state, so a captured iteration is cut here: the pool is asked between two graphs and its answer is
+        copied into the buffers the discriminator updates were captured on."""
+        from .graph import SegmentedIteration
+        if SegmentedIteration.active is None:
+            if getattr(self, '_pool_bypass', False):        # warm-up runs of a capture leave the history alone
+                return fake_A, fake_B
+            return self.pool([fake_A, fake_B])
+        out_A, out_B = torch.empty_like(fake_A), torch.empty_like(fake_B)
+
+        def ask_pool():
+            # the pool keeps copies: fake_A / fake_B are static buffers that the next replay overwrites
+            a, b = self.pool([fake_A.clone(), fake_B.clone()])
+            out_A.copy_(a)
+            out_B.copy_(b)
+        SegmentedIteration.cut(ask_pool)
+        return out_A, out_B
+
+    def iteration_runner(self, real_data):
+        """train_iteration as a chain of HIP graphs over a static input buffer, cut at the image pool (and
+        at the gradient exchanges when data parallel).  Returns run(real_data) -> the dict of losses."""
+        from .graph import iteration_runner
+        self._pool_bypass = True
+        try:
+            return iteration_runner(self.store, list(self.optims.values()), lambda a: self.train_iteration(a),
+                                    [real_data], self.world_size, self.process_group, segmented=True)
+        finally:
+            self._pool_bypass = False
 
     @staticmethod
     def totals(out):
@@ -235,7 +265,8 @@ class CycleGAN(object):
         Both are shuffled every epoch and paired by position; a batch is real_A | real_B on the
         channel axis.  Every `sample_every` iterations the translations of the current batch go to
         opts.sample_dir (sample_model, :216-236; 0 disables it).  Batches are prepared ahead of the GPU on a
-        background thread, in loop order (the crop / flip draws keep their sequence)."""
+        background thread, in loop order (the crop / flip draws keep their sequence); the iteration is
+        replayed as HIP graphs unless opts.use_graph is false."""
         from glob import glob
         from .misc import load_data, save_images
         from .prefetch import BatchPrefetcher, to_device
@@ -256,6 +287,7 @@ class CycleGAN(object):
             print(" [!] Load failed...")
         iters = 0
         out = None
+        run = None
         for epoch in range(opts.nEpochs):
             ia, ib = rng.permutation(len(dataA)), rng.permutation(len(dataB))
             batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // self.batch_size
@@ -271,7 +303,12 @@ class CycleGAN(object):
             feed = BatchPrefetcher(make, range(0, batch_idxs), depth=int(getattr(opts, 'prefetch_batches', 4)))
             for idx, host_batch in feed:
                 real = to_device(host_batch, dev)
-                out = self.train_iteration(real)
+                if getattr(opts, 'use_graph', True):
+                    if run is None:
+                        run = self.iteration_runner(real)
+                    out = run(real)
+                else:
+                    out = self.train_iteration(real)
                 counter += 1
                 print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
                 if sample_every and np.mod(counter, sample_every) == 1:

@@ -105,7 +105,7 @@ def build_parser():
                         help='train this many iterations on synthetic data of the model\'s input shape')
     parser.add_argument('--seed', type=int, default=0, help='seed of the weight initialisers and synthetic data')
     parser.add_argument('--use_graph', type=str2bool, default=True,
-                        help='replay the training iteration as HIP graphs (DCGAN, Text2Image); false issues every launch eagerly')
+                        help='replay the training iteration as HIP graphs; false issues every launch eagerly')
     parser.add_argument('--dataset_cache_gb', type=float, default=32.0,
                         help='DCGAN image files: keep the cropped / resized uint8 images in GPU memory after the first '
                              'epoch when they fit in this many GiB (0: decode the files every epoch)')

@@ -409,3 +409,33 @@ def test_text2image_train_loop_with_graph_replay_equals_eager_loop(tmp_path, cap
     for name, v in models[0][0].store.vars.items():
         assert torch.equal(v.data, models[1][0].store.vars[name].data), name
     assert (tmp_path / "ck1" / models[0][0].model_dir).exists()
+
+
+def test_cyclegan_train_loop_with_graphs_cut_at_the_image_pool_equals_eager_loop(tmp_path):
+    """CycleGAN.train replays the iteration as two HIP graphs with the image pool asked in between (its
+    history and its coin tosses are host state).  A pool of 2 is full after two iterations, so the other
+    four draw from it: same seeds, same in-memory data -> variables bit-identical to the eager loop's."""
+    from gan_amd.cyclegan import CycleGAN
+    rng = np.random.default_rng(6)
+    data_a = rng.uniform(-1, 1, (6, 32, 32, 3)).astype(np.float32)
+    data_b = rng.uniform(-1, 1, (6, 32, 32, 3)).astype(np.float32)
+    models, pools = [], []
+    for use_graph in (True, False):
+        o = cyc_opts(max_size=2, nEpochs=1, checkpoint_dir=str(tmp_path / ("ck%d" % use_graph)), use_graph=use_graph,
+                     sample_dir=str(tmp_path / "smp"), train_size=1e8)
+        m = CycleGAN(None, o)
+        if models:
+            m.store.load_state_dict(models[0][1])
+        models.append((m, m.store.state_dict()))
+        draws = np.random.RandomState(12)
+        m.pool.rand = draws.rand
+        m.pool.randint = lambda n, d=draws: int(d.rand() * n)
+        out = m.train(dataA=data_a, dataB=data_b, seed=3, sample_every=0)
+        assert all(np.isfinite(float(v)) for v in out.values())
+        pools.append(m.pool)
+    assert pools[0].num_img == pools[1].num_img == 2
+    for kept_g, kept_e in zip(pools[0].images, pools[1].images):
+        for a, b in zip(kept_g, kept_e):
+            assert torch.equal(a, b)
+    for name, v in models[0][0].store.vars.items():
+        assert torch.equal(v.data, models[1][0].store.vars[name].data), name

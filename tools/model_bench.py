@@ -16,7 +16,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from gan_amd import autotune  # noqa: E402
-from gan_amd.graph import CapturedIteration, model_state_restore, model_state_snapshot  # noqa: E402
 from gan_amd.main import build_parser  # noqa: E402
 
 
@@ -36,11 +35,6 @@ def timed(run, inputs, steps, warmup=3):
     vals = {k: float(v) for k, v in out.items() if getattr(v, "numel", lambda: 0)() == 1}
     assert np.isfinite(list(vals.values())).all(), vals
     return dt, vals
-
-
-def graphed(model, optims, fn, inputs):
-    return CapturedIteration(fn, inputs, snapshot=lambda: model_state_snapshot(model.store, optims),
-                             restore=lambda s: model_state_restore(model.store, optims, s))
 
 
 def main():
@@ -70,20 +64,18 @@ def main():
         m = Text2Image(None, o)
         inp = [dev(rng.uniform(0, 1, (64, 64, 64, 3))), dev(rng.uniform(0, 1, (64, 64, 64, 3))),
                dev(rng.standard_normal((64, 1024))), dev(rng.uniform(-1, 1, (64, 100)))]
-        fn = lambda a, b, c, d: {k: v for k, v in m.train_iteration(a, b, c, d).items() if k != 'generator'}
-        run = fn if args.no_graph else graphed(m, [m.d_optim, m.g_optim], fn, inp)
+        run = (lambda a, b, c, d: m.train_iteration(a, b, c, d)) if args.no_graph else m.iteration_runner(*inp)
         dt, vals = timed(run, inp, args.steps)
         print(json.dumps({"model": "Text2Image GAN-CLS 64x64, 1024-d captions, batch 64", "ms_per_step": round(dt * 1e3, 3),
                           "images_per_s": round(64 / dt, 1), "losses": vals}), flush=True)
     if args.model in ("cyclegan", "all"):
         from gan_amd.cyclegan import CycleGAN
-        o = P.parse_args("--model CycleGAN --batch_size 1 --dataset horse2zebra --max_size 0".split())
+        o = P.parse_args("--model CycleGAN --batch_size 1 --dataset horse2zebra".split())     # image pool of 50
         m = CycleGAN(None, o)
         inp = [dev(rng.uniform(-1, 1, (1, 256, 256, 6)))]
-        fn = lambda a: m.train_iteration(a)
-        run = fn if args.no_graph else graphed(m, list(m.optims.values()), fn, inp)
-        dt, vals = timed(run, inp, max(5, args.steps // 2))
-        print(json.dumps({"model": "CycleGAN 256x256 ResNet-9, batch 1 (image pool off for the static graph)",
+        run = (lambda a: m.train_iteration(a)) if args.no_graph else m.iteration_runner(inp[0])
+        dt, vals = timed(run, inp, max(60, args.steps))      # long enough for the pool to fill and be drawn from
+        print(json.dumps({"model": "CycleGAN 256x256 ResNet-9, batch 1, image pool 50 (two graphs, the pool asked in between)",
                           "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(1 / dt, 2), "losses": vals}), flush=True)
 
 
