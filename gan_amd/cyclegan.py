@@ -16,6 +16,7 @@ from . import variables as V
 from .cyclegan_module import (abs_criterion, discriminator, generator_resnet, generator_unet, mae_criterion,
                               sce_criterion)
 from .dcgan import latest_checkpoint, load_checkpoint, save_checkpoint
+from .dp import rank_of, rank_seed, shard_start
 from .optim import AdamOptimizer
 
 
@@ -73,6 +74,7 @@ class CycleGAN(object):
 
         self.model_dir = "%s_%s" % (self.dataset, self.image_size)
         self.world_size, self.process_group = world_size, process_group
+        self.rank = rank_of(world_size, process_group)
         self.store = store if store is not None else V.VariableStore(seed=getattr(opts, 'seed', 0))
 
         self._build_model()
@@ -272,7 +274,10 @@ class CycleGAN(object):
         from .prefetch import BatchPrefetcher, to_device
         opts = self.options
         dev = self.store.device
-        rng = np.random.RandomState(seed)
+        W, R = self.world_size, self.rank      # data parallel: same shuffles on every rank, consecutive batches each
+        order = rng = np.random.RandomState(seed)
+        if W > 1:
+            rng = np.random.RandomState(rank_seed(seed, R) + 1)       # this rank's crops and flips
         if dataA is None:
             dataA = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/trainA')))
             dataB = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/trainB')))
@@ -281,19 +286,19 @@ class CycleGAN(object):
         from_files = isinstance(dataA[0], str)
         counter = 1
         start_time = time.time()
-        if self.load(opts.checkpoint_dir):
-            print(" [*] Load SUCCESS")
-        else:
-            print(" [!] Load failed...")
+        loaded = self.load(opts.checkpoint_dir)
+        if R == 0:
+            print(" [*] Load SUCCESS" if loaded else " [!] Load failed...")
         iters = 0
         out = None
         run = None
         for epoch in range(opts.nEpochs):
-            ia, ib = rng.permutation(len(dataA)), rng.permutation(len(dataB))
-            batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // self.batch_size
+            ia, ib = order.permutation(len(dataA)), order.permutation(len(dataB))
+            batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // (self.batch_size * W)
 
             def make(idx, ia=ia, ib=ib):
-                sl = slice(idx * self.batch_size, (idx + 1) * self.batch_size)
+                start = shard_start(idx, R, W, self.batch_size)
+                sl = slice(start, start + self.batch_size)
                 if from_files:
                     return np.array([load_data((dataA[a], dataB[b]), flip=getattr(opts, 'flip', True),
                                                load_size=getattr(opts, 'load_size', 286), fine_size=self.image_size, rng=rng)
@@ -310,15 +315,16 @@ class CycleGAN(object):
                 else:
                     out = self.train_iteration(real)
                 counter += 1
-                print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
-                if sample_every and np.mod(counter, sample_every) == 1:
+                if R == 0:
+                    print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
+                if R == 0 and sample_every and np.mod(counter, sample_every) == 1:
                     fake_A, fake_B = self.forward_fakes(real)
                     sample_dir = getattr(opts, 'sample_dir', './samples')
                     if not os.path.exists(sample_dir):
                         os.makedirs(sample_dir)
                     save_images(fake_A.cpu().numpy(), [self.batch_size, 1], '{}/A_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
                     save_images(fake_B.cpu().numpy(), [self.batch_size, 1], '{}/B_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
-                if np.mod(counter, 1000) == 2:
+                if R == 0 and np.mod(counter, 1000) == 2:
                     self.save(opts.checkpoint_dir, counter)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:

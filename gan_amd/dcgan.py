@@ -28,6 +28,7 @@ from . import ops
 from . import variables as V
 from .ops import batch_norm, concat, conv2d, conv_cond_concat, deconv2d, linear, lrelu
 from .optim import AdamOptimizer
+from .dp import rank_of, rank_seed, shard_start
 
 
 def conv_out_size_same(size, stride):
@@ -60,6 +61,7 @@ class DCGAN(object):
 
         self.world_size = world_size
         self.process_group = process_group
+        self.rank = rank_of(world_size, process_group)
         self.stack_d_passes = True      # D update: D(real) and D(fake) as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
 
@@ -374,7 +376,10 @@ class DCGAN(object):
         loop body is replayed as HIP graphs (iteration_runner) unless opts.use_graph is false; the
         logging evaluations, the sampler and the checkpoints run eagerly between replays.  Image files
         travel as uint8 and are scaled on the GPU; the first epoch also leaves them in GPU memory
-        (opts.dataset_cache_gb, default 32: CelebA at 64x64 is 2.4 GB), so that later epochs decode nothing."""
+        (opts.dataset_cache_gb, default 32: CelebA at 64x64 is 2.4 GB), so that later epochs decode nothing.
+
+        Data parallel (world_size N): the ranks take consecutive batches of that sequence (N x batch_size
+        items per step, each rank its own z), rank 0 prints, samples and saves."""
         from glob import glob
         from .misc import save_images
         from .prefetch import BatchPrefetcher, to_device
@@ -387,9 +392,12 @@ class DCGAN(object):
             raise RuntimeError("no training data: pass data_X (and data_y) or data_files, or place MNIST under "
                                "./data/mnist / images under ./data/%s" % opts.dataset)
         dev = self.store.device
+        W, R = self.world_size, self.rank
         rng = np.random.RandomState(getattr(opts, 'seed', 0))
         sample_num = min(self.batch_size, 64)
         sample_z = torch.from_numpy(rng.uniform(-1, 1, size=(self.batch_size, self.z_dim)).astype(np.float32)).to(dev)
+        if R > 0:
+            rng = np.random.RandomState(rank_seed(getattr(opts, 'seed', 0), R))
         sample_y = None
         if self.y_dim and data_y is not None:
             sample_y = torch.from_numpy(np.asarray(data_y[:self.batch_size], dtype=np.float32)).to(dev)
@@ -398,16 +406,16 @@ class DCGAN(object):
         could_load, checkpoint_counter = self.load(self.checkpoint_dir)
         if could_load:
             self.counter = checkpoint_counter
-            print(" [*] Load SUCCESS")
-        else:
-            print(" [!] Load failed...")
+        if R == 0:
+            print(" [*] Load SUCCESS" if could_load else " [!] Load failed...")
         iters = 0
         use_graph = bool(getattr(opts, 'use_graph', True))
         run = None
         cache, cached = None, [0]          # uint8 images of the file data set in GPU memory; batches stored so far
         for epoch in range(opts.nEpochs):
             n_items = len(data_X) if data_X is not None else len(data_files)
-            batch_idxs = int(min(n_items, opts.train_size)) // opts.batch_size
+            batch_idxs = int(min(n_items, opts.train_size)) // (opts.batch_size * W)
+            items = lambda idx: slice(shard_start(idx, R, W, opts.batch_size), shard_start(idx, R, W, opts.batch_size) + opts.batch_size)
 
             from_files = data_X is None
             if from_files and cache is None and epoch == 0:
@@ -421,15 +429,14 @@ class DCGAN(object):
                 it, else from the input pipeline."""
                 if from_files and cache is not None and cached[0] >= batch_idxs:
                     for idx in range(0, batch_idxs):
-                        sl = slice(idx * opts.batch_size, (idx + 1) * opts.batch_size)
                         labels = None
                         if self.y_dim and data_y is not None:
-                            labels = torch.from_numpy(np.asarray(data_y[sl], dtype=np.float32)).to(dev)
-                        yield idx, self._scale_u8(cache[sl]), labels
+                            labels = torch.from_numpy(np.asarray(data_y[items(idx)], dtype=np.float32)).to(dev)
+                        yield idx, self._scale_u8(cache[idx * opts.batch_size:(idx + 1) * opts.batch_size]), labels
                     return
 
                 def make(idx):
-                    sl = slice(idx * opts.batch_size, (idx + 1) * opts.batch_size)
+                    sl = items(idx)
                     images = (np.asarray(data_X[sl], dtype=np.float32) if not from_files
                               else self._load_files_u8(data_files[sl], feed.pool_map))
                     labels = np.asarray(data_y[sl], dtype=np.float32) if (self.y_dim and data_y is not None) else None
@@ -463,11 +470,11 @@ class DCGAN(object):
                 else:
                     out = self.train_iteration(batch_images, batch_z, batch_labels, log_evals=log)
                 self.counter += 1
-                if log:
+                if log and R == 0:
                     print("Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f"
                           % (epoch, idx, batch_idxs, time.time() - start_time,
                              float(out['errD_fake']) + float(out['errD_real']), float(out['errG'])))
-                if sample_every and np.mod(self.counter, sample_every) == 1 and (not self.y_dim or sample_y is not None):
+                if R == 0 and sample_every and np.mod(self.counter, sample_every) == 1 and (not self.y_dim or sample_y is not None):
                     samples = self.sampler(sample_z, sample_y).cpu().numpy()[:sample_num]
                     manifold_h = int(np.ceil(np.sqrt(samples.shape[0])))
                     manifold_w = int(np.floor(np.sqrt(samples.shape[0])))
@@ -475,7 +482,7 @@ class DCGAN(object):
                         os.makedirs(sample_dir)
                     save_images(samples[:manifold_h * manifold_w], [manifold_h, manifold_w],
                                 os.path.join(sample_dir, 'train_{:02d}_{:04d}.png'.format(epoch, idx)))
-                if np.mod(self.counter, 500) == 2:
+                if R == 0 and np.mod(self.counter, 500) == 2:
                     self.save(opts.checkpoint_dir, self.counter)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:

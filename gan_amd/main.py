@@ -106,6 +106,9 @@ def build_parser():
     parser.add_argument('--seed', type=int, default=0, help='seed of the weight initialisers and synthetic data')
     parser.add_argument('--use_graph', type=str2bool, default=True,
                         help='replay the training iteration as HIP graphs; false issues every launch eagerly')
+    parser.add_argument('--dist_backend', default='nccl',
+                        help='collective backend when started by torch.distributed.run with several ranks: nccl (RCCL, '
+                             'one GPU per rank) or gloo (rehearsal: every rank on the one visible GPU)')
     parser.add_argument('--dataset_cache_gb', type=float, default=32.0,
                         help='DCGAN image files: keep the cropped / resized uint8 images in GPU memory after the first '
                              'epoch when they fit in this many GiB (0: decode the files every epoch)')
@@ -115,9 +118,11 @@ def build_parser():
 
 
 def synthetic_train(model, opts):
-    """N iterations on seeded synthetic inputs of the shapes and ranges the real loaders deliver."""
+    """N iterations on seeded synthetic inputs of the shapes and ranges the real loaders deliver
+    (data parallel: every rank draws its own)."""
     import torch
-    rng = np.random.default_rng(opts.seed)
+    rank = getattr(model, 'rank', 0)
+    rng = np.random.default_rng(opts.seed + 7919 * rank)
     dev = model.store.device
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     b = opts.batch_size
@@ -138,7 +143,7 @@ def synthetic_train(model, opts):
         else:
             s = opts.fine_size
             out = model.train_iteration(t(rng.uniform(-1, 1, (b, s, s, opts.input_nc + opts.output_nc))))
-        if it % max(1, opts.print_every) == 0:
+        if rank == 0 and it % max(1, opts.print_every) == 0:
             print("iter %4d  " % it + "  ".join("%s %.5f" % (k, float(v)) for k, v in sorted(out.items())
                                                  if getattr(v, 'numel', lambda: 0)() == 1))
     return out
@@ -153,16 +158,18 @@ def main(opts):
         opts.note = '_' + opts.note
 
     # path for checkpoint
-    if not os.path.exists(opts.checkpoint_dir):
-        os.makedirs(opts.checkpoint_dir)
+    os.makedirs(opts.checkpoint_dir, exist_ok=True)         # (several ranks may get here together)
 
     # path for sample images
     opts.sample_dir = join(opts.sample_dir, opts.model, opts.dataset)
     print('sample_dir = {}'.format(opts.sample_dir))
-    if not os.path.exists(opts.sample_dir):
-        os.makedirs(opts.sample_dir)
+    os.makedirs(opts.sample_dir, exist_ok=True)
 
     sess = None     # the reference's tf.Session has no counterpart: kernels launch on the current HIP stream
+    # one process per GPU under torch.distributed.run: every rank a replica, gradients summed per update
+    from .dp import init_from_env
+    world, rank = init_from_env(getattr(opts, 'dist_backend', 'nccl'))
+    dp = dict(world_size=world) if world > 1 else {}
     if opts.model == 'DCGAN':
         from .dcgan import DCGAN
         opts.y_dim = None
@@ -170,19 +177,20 @@ def main(opts):
             opts.y_dim = 10
             if opts.synthetic_iters:        # what load_mnist would have set (dcgan.py:72-75)
                 opts.c_dim = 1
-        model = DCGAN(sess, opts, load_data=not opts.synthetic_iters)
+        model = DCGAN(sess, opts, load_data=not opts.synthetic_iters, **dp)
     elif opts.model == 'Text2Image':
         from .text2image import Text2Image
-        model = Text2Image(sess, opts)
+        model = Text2Image(sess, opts, **dp)
     elif opts.model == 'CycleGAN':
         from .cyclegan import CycleGAN
-        model = CycleGAN(sess, opts)
+        model = CycleGAN(sess, opts, **dp)
     elif opts.model in ('TextDecoder', 'CrossModalRepr', 'CrossModalRepr_wWrong'):
         raise Exception("model %s is outside the accelerated GAN hot path" % opts.model)
     else:
         raise Exception("undefined model")
 
-    show_all_variables(model.store)
+    if rank == 0:
+        show_all_variables(model.store)
 
     # follow checkpoint_dir's convention
     model_dir = model.model_dir
@@ -218,4 +226,9 @@ def show_all_variables(store):
 
 
 if __name__ == '__main__':
-    main(build_parser().parse_args())
+    try:
+        main(build_parser().parse_args())
+    finally:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()

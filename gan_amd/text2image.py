@@ -17,6 +17,7 @@ import torch
 from . import ops
 from . import variables as V
 from .dcgan import latest_checkpoint, load_checkpoint, save_checkpoint
+from .dp import rank_of, rank_seed, shard_start
 from .optim import AdamOptimizer
 
 
@@ -70,6 +71,7 @@ class Text2Image(object):
         self.prefetch_batches = int(getattr(options, 'prefetch_batches', 4))
         self._runner = None
         self.world_size, self.process_group = world_size, process_group
+        self.rank = rank_of(world_size, process_group)
         self.stack_d_passes = True      # D update: the three D applications as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
 
@@ -289,12 +291,14 @@ class Text2Image(object):
         (get_training_batch, :389-397).  Batches are prepared ahead of the GPU on a background thread."""
         from .prefetch import BatchPrefetcher, to_device
         dev = self.store.device
-        rng = np.random.RandomState(seed)
+        W, R = self.world_size, self.rank          # data parallel: the ranks take consecutive batches
+        rng = np.random.RandomState(rank_seed(seed, R))
         n = len(images)
         iters = 0
 
         def make(batch_no):
-            sl = slice(batch_no * self.batch_size, (batch_no + 1) * self.batch_size)
+            start = shard_start(batch_no, R, W, self.batch_size)
+            sl = slice(start, start + self.batch_size)
             return (np.asarray(images[sl], dtype=np.float32),
                     np.asarray(images[rng.randint(0, n, self.batch_size)], dtype=np.float32),
                     np.asarray(captions[sl], dtype=np.float32),
@@ -302,20 +306,21 @@ class Text2Image(object):
 
         for i in range(self.nEpochs):
             batch_no = 0
-            feed = BatchPrefetcher(make, range(n // self.batch_size), depth=self.prefetch_batches)
+            feed = BatchPrefetcher(make, range(n // (self.batch_size * W)), depth=self.prefetch_batches)
             for _, host_batch in feed:
                 out = self._step(to_device(host_batch, dev))
-                d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
-                print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
-                    i, batch_no, n // self.batch_size, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
+                if R == 0:
+                    d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
+                    print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
+                        i, batch_no, n // (self.batch_size * W), d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
                 batch_no += 1
-                if (batch_no % self.save_every_batch) == 0:
+                if R == 0 and (batch_no % self.save_every_batch) == 0:
                     self.save(self.checkpoint_dir, batch_no)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
                     feed.close()
                     return
-            if i % 5 == 0:
+            if R == 0 and i % 5 == 0:
                 self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))
 
     # ---------------------------------------------------------------------------------- flowers files
@@ -399,26 +404,30 @@ class Text2Image(object):
         """The training loop of text2image.py:224-285 over the flowers files (batches read ahead of the GPU)."""
         from .prefetch import BatchPrefetcher, to_device
         dev = self.store.device
-        rng = random.Random(seed)
+        W, R = self.world_size, self.rank          # data parallel: the ranks take consecutive batches
+        if W > 1 and seed is None:
+            seed = 0                               # every rank must shuffle the image list the same way
+        rng = random.Random(rank_seed(seed, R))
         loaded = self.load_training_data(data_dir, self.dataset, seed)
         if loaded['data_length'] == 0:
             raise RuntimeError("no flowers training images found under %s" % (data_dir or self.data_dir))
-        n_batch = loaded['data_length'] // self.batch_size
+        n_batch = loaded['data_length'] // (self.batch_size * W)
         iters, out = 0, None
-        n_feeds = (loaded['data_length'] + self.batch_size - 1) // self.batch_size     # the last one wraps around
+        n_feeds = (loaded['data_length'] + self.batch_size * W - 1) // (self.batch_size * W)   # the last one wraps around
         for i in range(self.nEpochs):
             batch_no = 0
             # one producer thread draws the random numbers of the batches in the order of the inline loop
-            feed = BatchPrefetcher(lambda b: self.get_training_batch(b, loaded, data_dir, rng), range(n_feeds),
+            feed = BatchPrefetcher(lambda b: self.get_training_batch(b * W + R, loaded, data_dir, rng), range(n_feeds),
                                    depth=self.prefetch_batches)
             for _, host_batch in feed:
                 real, wrong, cap, z, image_files = host_batch
                 out = self._step(to_device((real, wrong, cap, z), dev))
-                d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
-                print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
-                    i, batch_no, n_batch, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
+                if R == 0:
+                    d1, d2, d3 = float(out['d_loss1']), float(out['d_loss2']), float(out['d_loss3'])
+                    print("epoch {} batch {}/{} (d1,d2,d3)=({:.4f}, {:.4f}, {:.4f}) (D,G)=({:.4f}, {:.4f})".format(
+                        i, batch_no, n_batch, d1, d2, d3, d1 + d2 + d3, float(out['g_loss_2'])))
                 batch_no += 1
-                if (batch_no % self.save_every_batch) == 0:
+                if R == 0 and (batch_no % self.save_every_batch) == 0:
                     print("Saving Images, Model")
                     self.save_for_vis(real.numpy(), out['generator'].cpu().numpy(), image_files)
                     self.save(self.checkpoint_dir, batch_no)
@@ -426,7 +435,7 @@ class Text2Image(object):
                 if max_iters is not None and iters >= max_iters:
                     feed.close()
                     return out
-            if i % 5 == 0:
+            if R == 0 and i % 5 == 0:
                 self.save(self.checkpoint_dir, batch_no, note="epoch{}".format(i))
         return out
 

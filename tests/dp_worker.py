@@ -9,6 +9,8 @@ two ranks share cuda:0 and RCCL would refuse the duplicate device) and writes wh
          all-reduce through AdamOptimizer.all_reduce.
   gpu  : the real DCGAN data-parallel iteration on cuda:0 (eager, then the segmented HIP-graph
          runner from the same start state).
+  train: DCGAN.train over an in-memory data set whose items carry their index: which items each rank
+         consumed, who printed / sampled / saved, and the trained variables.
 """
 import os
 import sys
@@ -128,6 +130,35 @@ def run_gpu(out, rank, world):
     np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
 
 
+def run_train(out, rank, world):
+    from test_gpu_dcgan import make_opts
+    from gan_amd.dcgan import DCGAN
+    torch.cuda.set_device(0)
+    opts = make_opts(seed=rank, checkpoint_dir=os.path.join(out, "ck"), sample_dir=os.path.join(out, "smp"),
+                     print_every=2, use_graph=True)
+    model = DCGAN(None, opts, world_size=world, load_data=False)
+    n = 5 * opts.batch_size * world + 3
+    data_X = np.random.default_rng(1).uniform(-1, 1, (n, 16, 16, 3)).astype(np.float32)
+    data_X[:, 0, 0, 0] = np.arange(n) / float(n)               # item i says so in its first pixel
+    seen = []
+    make_runner = model.iteration_runner
+
+    def recording_runner(images, z, y=None):
+        run = make_runner(images, z, y)
+
+        def wrapped(im, zz, yy=None):
+            seen.append(np.round(im[:, 0, 0, 0].cpu().numpy() * n).astype(np.int64))
+            return run(im, zz, yy)
+        return wrapped
+    model.iteration_runner = recording_runner
+    model.train(data_X=data_X, sample_every=3)
+    res = {"seen": np.array(seen), "counter": np.array([model.counter]),
+           "steps": np.array([model.d_optim.steps_taken, model.g_optim.steps_taken])}
+    for name, v in model.store.vars.items():
+        res["final/" + name] = v.data.cpu().numpy()
+    np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -137,7 +168,7 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mark("joined")
     try:
-        (run_cpu if mode == "cpu" else run_gpu)(out, rank, world)
+        {"cpu": run_cpu, "gpu": run_gpu, "train": run_train}[mode](out, rank, world)
         dist.barrier()
     finally:
         dist.destroy_process_group()

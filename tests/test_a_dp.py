@@ -206,3 +206,67 @@ def test_dcgan_data_parallel_two_ranks_match_oracle(tmp_path):
         else:
             np.testing.assert_array_equal(got[0][k], got[1][k])
     assert differs > 0
+
+
+@pytest.mark.gpu
+def test_train_loop_shards_the_batches_over_the_ranks(tmp_path):
+    """DCGAN.train on two ranks: in step i rank r trains on batch 2i + r of the sequence the one-device loop
+    walks through (graph replay, prefetched batches), the replicas stay bit-identical, and only rank 0
+    prints, samples and writes the checkpoint."""
+    world, bs = 2, 8
+    got = launch("train", tmp_path, world)
+    for r in range(world):
+        want = np.array([np.arange((i * world + r) * bs, (i * world + r + 1) * bs) for i in range(5)])
+        np.testing.assert_array_equal(got[r]["seen"], want)
+        assert int(got[r]["counter"][0]) == 6 and list(got[r]["steps"]) == [5, 10]
+    moved = 0
+    for k in got[0].files:
+        if k.startswith("final/") and "moving_" not in k:
+            np.testing.assert_array_equal(got[0][k], got[1][k])
+            assert np.isfinite(got[0][k]).all()
+            moved += 1
+    assert moved > 20
+    logs = [open(os.path.join(str(tmp_path), "rank%d.log" % r)).read() for r in range(world)]
+    assert logs[0].count("Epoch: [") == 3 and "Epoch: [" not in logs[1]
+    assert os.path.exists(os.path.join(str(tmp_path), "smp", "train_00_0002.png"))
+    assert os.path.isdir(os.path.join(str(tmp_path), "ck", "DCGAN_synthetic_8_16_16"))      # counter 2 -> checkpoint
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("argv", [
+    "--model DCGAN --dataset celebA --output_height 16 --batch_size 8 --gf_dim 8 --df_dim 8 --z_dim 16",
+    "--model CycleGAN --dataset horse2zebra --batch_size 1 --fine_size 32 --gf_dim 4 --df_dim 4 --max_size 2",
+])
+def test_command_line_joins_a_two_rank_job(argv, tmp_path):
+    """`python -m gan_amd.main ...` under the environment torch.distributed.run gives its workers: both ranks
+    join the group (gloo here: one visible GPU), train as replicas and exit cleanly; rank 0 alone reports."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-u", "-m", "gan_amd.main"] + argv.split() + [
+        "--synthetic_iters", "3", "--dist_backend", "gloo", "--checkpoint_dir", str(tmp_path / "ck"),
+        "--sample_dir", str(tmp_path / "smp")]
+    procs, logs = [], []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
+        logs.append(open(str(tmp_path / ("rank%d.log" % rank)), "wb"))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=os.path.dirname(HERE), stdout=logs[-1], stderr=subprocess.STDOUT))
+    t0 = time.time()
+    try:
+        while any(p.poll() is None for p in procs) and time.time() - t0 < 300:
+            if any(p.poll() not in (None, 0) for p in procs):
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for f in logs:
+            f.close()
+    texts = [open(str(tmp_path / ("rank%d.log" % r))).read() for r in range(2)]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d exited with %s:\n%s" % (r, p.returncode, texts[r][-3000:])
+    assert texts[0].count("iter ") == 3 and "Total size of variables" in texts[0]
+    assert "iter " not in texts[1] and "Total size of variables" not in texts[1]
