@@ -318,12 +318,14 @@ class CycleGAN(object):
                 if R == 0:
                     print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
                 if R == 0 and sample_every and np.mod(counter, sample_every) == 1:
-                    fake_A, fake_B = self.forward_fakes(real)
                     sample_dir = getattr(opts, 'sample_dir', './samples')
-                    if not os.path.exists(sample_dir):
-                        os.makedirs(sample_dir)
-                    save_images(fake_A.cpu().numpy(), [self.batch_size, 1], '{}/A_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
-                    save_images(fake_B.cpu().numpy(), [self.batch_size, 1], '{}/B_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
+                    if not self.sample_model(sample_dir, epoch, idx):
+                        # no testA / testB files (in-memory data): the translations of the current batch
+                        fake_A, fake_B = self.forward_fakes(real)
+                        if not os.path.exists(sample_dir):
+                            os.makedirs(sample_dir)
+                        save_images(fake_A.cpu().numpy(), [self.batch_size, 1], '{}/A_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
+                        save_images(fake_B.cpu().numpy(), [self.batch_size, 1], '{}/B_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
                 if R == 0 and np.mod(counter, 1000) == 2:
                     self.save(opts.checkpoint_dir, counter)
                 iters += 1
@@ -331,6 +333,53 @@ class CycleGAN(object):
                     feed.close()
                     return out
         return out
+
+    def sample_model(self, sample_dir, epoch, idx, rng=np.random):
+        """cyclegan.py:216-236: translate batch_size shuffled testA / testB pairs and write the real and the
+        translated images as <sample_dir>/{A,B}_<epoch>_<idx>[_real].jpg.  Returns False (nothing written)
+        when the data set has no test images."""
+        from glob import glob
+        from .misc import load_data, save_images
+        dataA = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/testA')))
+        dataB = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/testB')))
+        if len(dataA) < self.batch_size or len(dataB) < self.batch_size:
+            return False
+        rng.shuffle(dataA)
+        rng.shuffle(dataB)
+        batch_files = zip(dataA[:self.batch_size], dataB[:self.batch_size])
+        sample_images = np.array([load_data(f, False, True, fine_size=self.image_size) for f in batch_files]).astype(np.float32)
+        fake_A, fake_B = self.forward_fakes(torch.from_numpy(sample_images).to(self.store.device))
+        if not os.path.exists(sample_dir):
+            os.makedirs(sample_dir)
+        save_images(sample_images[:, :, :, 0:3], [self.batch_size, 1], '{}/A_{:02d}_{:04d}_real.jpg'.format(sample_dir, epoch, idx))
+        save_images(sample_images[:, :, :, 3:6], [self.batch_size, 1], '{}/B_{:02d}_{:04d}_real.jpg'.format(sample_dir, epoch, idx))
+        save_images(fake_A.cpu().numpy(), [self.batch_size, 1], '{}/A_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
+        save_images(fake_B.cpu().numpy(), [self.batch_size, 1], '{}/B_{:02d}_{:04d}.jpg'.format(sample_dir, epoch, idx))
+        return True
+
+    def test_files(self, opts):
+        """cyclegan.py:238-265: translate every testA (AtoB) or testB (BtoA) image with the checkpointed
+        generator and write <test_dir>/A2B_<name> or B2A_<name>.  Returns the written paths."""
+        from glob import glob
+        from .misc import load_test_data, save_images
+        if opts.which_direction == 'AtoB':
+            sample_files = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/testA')))
+        elif opts.which_direction == 'BtoA':
+            sample_files = sorted(glob('./{}/*.jpg'.format(self.dataset_dir + '/testB')))
+        else:
+            raise Exception('--which_direction must be AtoB or BtoA')
+        print(" [*] Load SUCCESS" if self.load(opts.checkpoint_dir) else " [!] Load failed...")
+        if not os.path.exists(opts.test_dir):
+            os.makedirs(opts.test_dir)
+        written = []
+        for sample_file in sample_files:
+            print('Processing image: ' + sample_file)
+            sample_image = np.array([load_test_data(sample_file, self.image_size)]).astype(np.float32)
+            fake = self.test(torch.from_numpy(sample_image).to(self.store.device), opts.which_direction)
+            prefix = 'A2B_' if opts.which_direction == 'AtoB' else 'B2A_'
+            written.append('{}/{}{}'.format(opts.test_dir, prefix, sample_file.split('/')[-1]))
+            save_images(fake.cpu().numpy(), [1, 1], written[-1])
+        return written
 
     def test(self, images, which_direction='AtoB'):
         """cyclegan.py:238-265 without the file I/O: translate a batch with one generator."""

@@ -207,9 +207,17 @@ def main(opts):
     elif opts.phase == 'valid':
         raise Exception("phase 'valid' is not used by the reference's GAN models")
     else:
+        if opts.model == 'CycleGAN':
+            return model.test_files(opts)       # cyclegan.py:238-265 (the reference's main only loads)
         loaded = model.load(opts.checkpoint_dir)
         if not (loaded[0] if isinstance(loaded, tuple) else loaded):
             raise Exception("[!] Train a model first, then run test mode")
+
+    # Below is codes for visualization (main.py:98-101)
+    if opts.model == 'DCGAN' and rank == 0:
+        from .misc import visualize
+        OPTION = 1
+        visualize(model, opts, OPTION)
     return None
 
 

@@ -165,3 +165,45 @@ def load_data(image_path, flip=True, is_test=False, load_size=286, fine_size=256
     img_A = img_A / 127.5 - 1.
     img_B = img_B / 127.5 - 1.
     return np.concatenate((img_A, img_B), axis=2)
+
+
+# ------------------------------------------------------------------------------------ DCGAN visualisation
+def visualize(model, config, option, out_dir='./samples', rng=np.random):
+    """misc.py:175-198, options 0 and 1: sampler grids written under ./samples.  Option 0: one grid for
+    z ~ U(-0.5, 0.5).  Option 1: for each of the first 100 z coordinates one grid in which that coordinate
+    runs over arange(0, 1, 1/batch_size) and the others are zero (MNIST: with random class labels).
+    Options 2-4 build GIF animations with moviepy, which is outside this path."""
+    import math
+    from time import gmtime, strftime
+    import torch
+    if option not in (0, 1):
+        raise NotImplementedError("visualize: options 2-4 write GIFs through moviepy")
+    import os
+    if not os.path.exists(out_dir):
+        os.makedirs(out_dir)
+    dev = model.store.device
+    image_frame_dim = int(math.ceil(config.batch_size ** .5))
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    written = []
+    if option == 0:
+        z_sample = rng.uniform(-0.5, 0.5, size=(config.batch_size, model.z_dim))
+        samples = model.sampler(to_dev(z_sample)).cpu().numpy()
+        written.append(save_images(samples, [image_frame_dim, image_frame_dim],
+                                   os.path.join(out_dir, 'test_%s.png' % strftime("%Y%m%d%H%M%S", gmtime()))))
+        return written
+    values = np.arange(0, 1, 1. / config.batch_size)
+    for idx in range(min(100, model.z_dim)):
+        print(" [*] %d" % idx)
+        z_sample = np.zeros([config.batch_size, model.z_dim])
+        for kdx, z in enumerate(z_sample):
+            z[idx] = values[kdx]
+        if config.dataset == "mnist":
+            y = rng.choice(10, config.batch_size)
+            y_one_hot = np.zeros((config.batch_size, 10))
+            y_one_hot[np.arange(config.batch_size), y] = 1
+            samples = model.sampler(to_dev(z_sample), to_dev(y_one_hot))
+        else:
+            samples = model.sampler(to_dev(z_sample))
+        written.append(save_images(samples.cpu().numpy(), [image_frame_dim, image_frame_dim],
+                                   os.path.join(out_dir, 'test_arange_%s.png' % (idx))))
+    return written
