@@ -272,6 +272,7 @@ class CycleGAN(object):
         from glob import glob
         from .misc import load_data, save_images
         from .prefetch import BatchPrefetcher, to_device
+        from .summary import ScalarLog
         opts = self.options
         dev = self.store.device
         W, R = self.world_size, self.rank      # data parallel: same shuffles on every rank, consecutive batches each
@@ -292,6 +293,7 @@ class CycleGAN(object):
         iters = 0
         out = None
         run = None
+        scalars = ScalarLog(getattr(opts, 'log_dir', None), enabled=(R == 0 and bool(getattr(opts, 'write_scalars', False))))
         for epoch in range(opts.nEpochs):
             ia, ib = order.permutation(len(dataA)), order.permutation(len(dataB))
             batch_idxs = int(min(min(len(dataA), len(dataB)), getattr(opts, 'train_size', 1e8))) // (self.batch_size * W)
@@ -317,6 +319,8 @@ class CycleGAN(object):
                 counter += 1
                 if R == 0:
                     print("Epoch: [%2d] [%4d/%4d] time: %4.4f" % (epoch, idx, batch_idxs, time.time() - start_time))
+                    if scalars.path:
+                        scalars.add(counter, **self.totals(out))
                 if R == 0 and sample_every and np.mod(counter, sample_every) == 1:
                     sample_dir = getattr(opts, 'sample_dir', './samples')
                     if not self.sample_model(sample_dir, epoch, idx):
@@ -331,7 +335,9 @@ class CycleGAN(object):
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
                     feed.close()
+                    scalars.close()
                     return out
+        scalars.close()
         return out
 
     def sample_model(self, sample_dir, epoch, idx, rng=np.random):

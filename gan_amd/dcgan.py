@@ -383,6 +383,7 @@ class DCGAN(object):
         from glob import glob
         from .misc import save_images
         from .prefetch import BatchPrefetcher, to_device
+        from .summary import ScalarLog
         opts = self.opts
         if data_X is None and data_files is None:
             data_X, data_y = self.data_X, self.data_y
@@ -410,6 +411,7 @@ class DCGAN(object):
             print(" [*] Load SUCCESS" if could_load else " [!] Load failed...")
         iters = 0
         use_graph = bool(getattr(opts, 'use_graph', True))
+        scalars = ScalarLog(getattr(opts, 'log_dir', None), enabled=(R == 0 and bool(getattr(opts, 'write_scalars', False))))
         run = None
         cache, cached = None, [0]          # uint8 images of the file data set in GPU memory; batches stored so far
         for epoch in range(opts.nEpochs):
@@ -474,6 +476,8 @@ class DCGAN(object):
                     print("Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f"
                           % (epoch, idx, batch_idxs, time.time() - start_time,
                              float(out['errD_fake']) + float(out['errD_real']), float(out['errG'])))
+                    scalars.add(self.counter, d_loss_real=out['d_loss_real'], d_loss_fake=out['d_loss_fake'],
+                                d_loss=float(out['d_loss_real']) + float(out['d_loss_fake']), g_loss=out['g_loss_2'])
                 if R == 0 and sample_every and np.mod(self.counter, sample_every) == 1 and (not self.y_dim or sample_y is not None):
                     samples = self.sampler(sample_z, sample_y).cpu().numpy()[:sample_num]
                     manifold_h = int(np.ceil(np.sqrt(samples.shape[0])))
@@ -486,7 +490,9 @@ class DCGAN(object):
                     self.save(opts.checkpoint_dir, self.counter)
                 iters += 1
                 if max_iters is not None and iters >= max_iters:
+                    scalars.close()
                     return                  # (closing the generator stops the input pipeline)
+        scalars.close()
 
     # ------------------------------------------------------------------------------------ data
     def load_mnist(self):

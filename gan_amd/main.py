@@ -106,6 +106,9 @@ def build_parser():
     parser.add_argument('--seed', type=int, default=0, help='seed of the weight initialisers and synthetic data')
     parser.add_argument('--use_graph', type=str2bool, default=True,
                         help='replay the training iteration as HIP graphs; false issues every launch eagerly')
+    parser.add_argument('--write_scalars', type=str2bool, default=True,
+                        help='append the losses of every logged step to <log_dir>/<model_dir>/scalars.jsonl '
+                             '(stands in for the tf.summary scalars)')
     parser.add_argument('--dist_backend', default='nccl',
                         help='collective backend when started by torch.distributed.run with several ranks: nccl (RCCL, '
                              'one GPU per rank) or gloo (rehearsal: every rank on the one visible GPU)')

@@ -145,6 +145,10 @@ def test_reference_directory_layout_end_to_end(tmp_path, monkeypatch):
     assert len(grids) == 12                                  # one per z coordinate (100 when z_dim >= 100)
     assert np.asarray(Image.open(str(grids[0]))).shape == (16 * 3, 16 * 3, 3)      # ceil(sqrt(8)) = 3
     assert (tmp_path / "checkpoint" / "DCGAN_faces_8_16_16").exists()              # counter 2
+    import json
+    recs = [json.loads(l) for l in open(str(tmp_path / "logs" / "DCGAN_faces_8_16_16" / "scalars.jsonl"))]
+    assert [r["step"] for r in recs] == [2, 4]               # print_every 100: the first batch of each epoch
+    assert all(abs(r["d_loss"] - r["d_loss_real"] - r["d_loss_fake"]) < 1e-6 and np.isfinite(r["g_loss"]) for r in recs)
 
     for part in ("trainA", "trainB", "testA", "testB"):
         images("data/h2z/" + part, 3, (40, 40))
@@ -154,6 +158,8 @@ def test_reference_directory_layout_end_to_end(tmp_path, monkeypatch):
     smp = tmp_path / "samples" / "CycleGAN" / "h2z"
     assert sorted(p.name for p in smp.glob("*.jpg")) == ["A_33_0000.jpg", "A_33_0000_real.jpg", "B_33_0000.jpg",
                                                          "B_33_0000_real.jpg"]
+    recs = [json.loads(l) for l in open(str(tmp_path / "logs" / "h2z_32" / "scalars.jsonl"))]
+    assert len(recs) == 102 and sorted(recs[0]) == ["da_loss", "db_loss", "g_loss_a2b", "g_loss_b2a", "step", "time"]
     written = main(parse(common + ["--phase", "test", "--which_direction", "AtoB"]))
     assert [p.split("/")[-1] for p in written] == ["A2B_000.jpg", "A2B_001.jpg", "A2B_002.jpg"]
     assert np.asarray(Image.open(written[0])).shape == (32, 32, 3)
