@@ -277,6 +277,17 @@ class Text2Image(object):
                                 lambda a, b, c, d: self.train_iteration(a, b, c, d),
                                 [real_image, wrong_image, real_caption, z], self.world_size, self.process_group, segmented)
 
+    def _resume(self):
+        """text2image.py:237-238: `--resume_model <path>` restores that checkpoint before training starts
+        (the file save() wrote; its .npz suffix may be left out)."""
+        path = self.resume_model
+        if not path:
+            return False
+        if not os.path.exists(path) and os.path.exists(path + '.npz'):
+            path = path + '.npz'
+        load_checkpoint(self.store, {'d': self.d_optim, 'g': self.g_optim}, path)
+        return True
+
     def _step(self, batch):
         """One iteration on a device batch (real, wrong, captions, z): graph replay unless use_graph is off."""
         if not self.use_graph:
@@ -293,6 +304,7 @@ class Text2Image(object):
         dev = self.store.device
         W, R = self.world_size, self.rank          # data parallel: the ranks take consecutive batches
         rng = np.random.RandomState(rank_seed(seed, R))
+        self._resume()
         n = len(images)
         iters = 0
 
@@ -408,6 +420,7 @@ class Text2Image(object):
         if W > 1 and seed is None:
             seed = 0                               # every rank must shuffle the image list the same way
         rng = random.Random(rank_seed(seed, R))
+        self._resume()
         loaded = self.load_training_data(data_dir, self.dataset, seed)
         if loaded['data_length'] == 0:
             raise RuntimeError("no flowers training images found under %s" % (data_dir or self.data_dir))

@@ -409,6 +409,23 @@ def test_text2image_train_loop_with_graph_replay_equals_eager_loop(tmp_path, cap
     for name, v in models[0][0].store.vars.items():
         assert torch.equal(v.data, models[1][0].store.vars[name].data), name
     assert (tmp_path / "ck1" / models[0][0].model_dir).exists()
+    # --resume_model (text2image.py:237-238): a model started from the checkpoint written after batch 2
+    # trains on from there -- one more epoch from that state equals one more epoch of the saved model
+    ckpt = str(tmp_path / "ck1" / models[0][0].model_dir / "Text2Image.model-2")
+    o = t2i_opts()
+    o.use_graph, o.checkpoint_dir, o.save_every_batch, o.resume_model = True, str(tmp_path / "ck3"), 100, ckpt
+    resumed = Text2Image(None, o)
+    assert resumed.resume_model == ckpt and resumed._resume()
+    from gan_amd.dcgan import load_checkpoint
+    o2 = t2i_opts()
+    o2.use_graph, o2.checkpoint_dir, o2.save_every_batch = True, str(tmp_path / "ck4"), 100
+    twin = Text2Image(None, o2)
+    load_checkpoint(twin.store, {'d': twin.d_optim, 'g': twin.g_optim}, ckpt + ".npz")
+    assert twin.d_optim.steps_taken == 2 and resumed.d_optim.steps_taken == 2
+    resumed.train(images, captions, seed=9)
+    twin.train(images, captions, seed=9)
+    for name, v in twin.store.vars.items():
+        assert torch.equal(v.data, resumed.store.vars[name].data), name
 
 
 def test_cyclegan_train_loop_with_graphs_cut_at_the_image_pool_equals_eager_loop(tmp_path):
