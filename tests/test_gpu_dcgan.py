@@ -54,12 +54,6 @@ def to_dev(*arrs):
     return [None if a is None else torch.from_numpy(a).cuda() for a in arrs]
 
 
-def check_grad(name, got, ref, tol=2e-4):
-    """A bias that feeds a batch norm has an exactly-zero true gradient; both sides then hold only
-    rounding noise, which is compared against an absolute bound instead of relatively."""
-    raise AssertionError("superseded by gpu_util.check_group_grads")
-
-
 def grads_by_name(group):
     return {v.name: v.grad.detach().cpu().numpy() for v in group.variables}
 
