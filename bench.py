@@ -96,6 +96,49 @@ class ContractionTimer(object):
         return tot_ms, tot_fl, len(self.records), per
 
 
+class ContractionRecorder(ContractionTimer):
+    """Records every conv / deconv / linear C-ABI call (function, arguments, nominal FLOPs) while letting
+    it through, so that the same launches can be issued again on the same buffers."""
+
+    def _wrap(self, name, fn):
+        is_conv = name in self.CONV
+
+        def call(*args):
+            flops = conv_flops(args[0]._obj) if is_conv else 2.0 * args[0] * args[1] * args[2]
+            self.records.append((fn, args, flops))
+            return fn(*args)
+        return call
+
+
+def contraction_sequence_time(model, batch, L, replays=20):
+    """Duration of the contraction launches of ONE iteration with nothing in between: the iteration is
+    captured once (never replayed) with every contraction call recorded; its buffers stay reserved in that
+    graph's memory pool, so the recorded calls are issued again, alone, into a second graph, which is
+    replayed `replays` times between two HIP events.  Returns (ms per iteration, FLOP per iteration, calls)."""
+    from gan_amd._lib import stream
+    holder = torch.cuda.CUDAGraph()
+    with ContractionRecorder(L) as rec:
+        with torch.cuda.graph(holder):
+            model.train_iteration(*batch)
+    only = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(only):
+        for fn, args, _ in rec.records:
+            rc = fn(*(tuple(args[:-1]) + (stream(),)))         # the stream is every entry point's last argument
+            if rc != 0:
+                raise SystemExit("re-issuing a recorded contraction call failed: %s" % L.lib.gan_last_error().decode())
+    only.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        only.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / replays
+    del only, holder
+    return ms, sum(r[2] for r in rec.records), len(rec.records)
+
+
 def cpu_baseline(iters):
     """The numpy oracle's restatement of the same iteration on the host cores ("port", not TensorFlow)."""
     from oracle import autodiff as A
@@ -215,6 +258,15 @@ def main():
         for i in range(timer_iters):
             model.train_iteration(*pool[i % len(pool)])
         ms, flops, calls, per = tm.summary()
+    eager_ms, eager_achieved = ms / timer_iters, flops / (ms * 1e-3) / 1e12
+    method = "HIP events around every contraction call of %d eager iterations" % timer_iters
+    if world == 1 and pg is None:
+        # one GPU: the same launches replayed back to back as a HIP graph (no host dispatch gap between a
+        # contraction kernel and its slab reduction), which is how they run in the timed region
+        seq_ms, seq_flops, seq_calls = contraction_sequence_time(model, pool[0], _lib)
+        ms, flops, calls, timer_iters = seq_ms, seq_flops, seq_calls, 1
+        method = ("HIP events around 20 replays of a HIP graph holding only the %d contraction calls of one iteration, "
+                  "on the buffers of a captured iteration" % seq_calls)
     achieved = flops / (ms * 1e-3) / 1e12
     exact = bool(_lib.lib.gan_get_exact_f32())
     # `achieved` counts the ALGORITHMIC fp32 FLOP of the convolutions.  The default arithmetic forms every
@@ -229,7 +281,8 @@ def main():
                            "fp32 operands split exactly into 3 bf16 parts, 6 of the 9 part products on the bf16 MFMA, "
                            "fp32 accumulation (error at the fp32 rounding level); peak = bf16 dense peak / 6"),
             "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "flop_per_step": round(flops / timer_iters / 1e9, 2), "kernel_ms_per_step": round(ms / timer_iters, 3)}
+            "flop_per_step": round(flops / timer_iters / 1e9, 2), "kernel_ms_per_step": round(ms / timer_iters, 3),
+            "method": method, "eager_event_ms_per_step": round(eager_ms, 3), "eager_event_achieved": round(eager_achieved, 2)}
     if args.detail and rank == 0:
         for k, (n, t_ms, fl) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             sys.stderr.write("%-70s calls %3d  %8.3f ms/iter  %7.2f TFLOP/s\n"
