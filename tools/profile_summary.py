@@ -5,7 +5,8 @@ replays only (start-up tuning, warm-up, capture and the eager roofline pass are 
     python tools/profile_summary.py <kernel_trace.csv> <steps> <out.md> [<out.csv>]
 
 An iteration ends with the generator's Adam step, the third adam_apply_kernel of the iteration; the
-trace ends with 3 eager iterations (bench.py's roofline pass) preceded by <steps> timed replays."""
+trace ends with 3 eager iterations (bench.py's roofline pass; the replays of the contraction-only graph that
+follow them hold no Adam kernels) preceded by <steps> timed replays."""
 import collections
 import csv
 import re
