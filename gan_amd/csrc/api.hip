@@ -17,11 +17,13 @@ void set_exact_f32(int on);
 int get_exact_f32();
 size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
-                   int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what);
+                   int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
+                   const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
 // elementwise.hip
 size_t colsum_ws_bytes(long rows, int c);
-int colsum(const float* x, float* out, long rows, int c, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-           const char* what);
+int colsum_partial(const float* x, long rows, int c, void* ws, size_t ws_bytes, hipStream_t st, const char* what,
+                   ColsumFinal* job);
+int colsum_final(const ColsumFinal& job, hipStream_t st, const char* what);
 
 static thread_local char g_error[512] = "";
 
@@ -49,6 +51,36 @@ static gan_conv_geom linear_geom(int rows, int in_dim, int out_dim) {
 
 static size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// Weight gradient + bias gradient of one layer.  The bias gradient is the column sum of `dy_rows` ([rows][c]).
+// Its first stage runs first, into the workspace behind the split-K slabs; its last stage rides on the slab
+// reduction's launch when there is one, so the pair costs one launch more than the weight gradient alone.
+static int wgrad_with_bias(const gan_conv_geom& g, const float* a, const float* b, float* dw, float* db,
+                           const float* dy_rows, long rows, int c, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                           const char* what) {
+    if (db == nullptr)
+        return run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, ws_bytes, st, what);
+    if (getenv("GAN_HIP_SEPARATE_COLSUM")) {        // test knob: the column sum as two launches of its own, afterwards
+        if (int rc = run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, ws_bytes, st, what)) return rc;
+        ColsumFinal sep;
+        if (int rc = colsum_partial(dy_rows, rows, c, ws, ws_bytes, st, what, &sep)) return rc;
+        sep.out = db;
+        sep.accumulate = accumulate;
+        return colsum_final(sep, st, what);
+    }
+    const size_t off = align256(igemm_ws_bytes_geom(MODE_WGRAD, g));
+    GAN_CHECK_ARG(ws && ws_bytes >= off, "%s: workspace of %zu bytes needed, %zu given", what, off, ws_bytes);
+    ColsumFinal job;
+    if (int rc = colsum_partial(dy_rows, rows, c, static_cast<char*>(ws) + off, ws_bytes - off, st, what, &job)) return rc;
+    job.out = db;
+    job.accumulate = accumulate;
+    int done = 0;
+    if (int rc = run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, ws_bytes, st, what, &job, &done))
+        return rc;
+    return done ? 0 : colsum_final(job, st, what);
+}
+
 }  // namespace gan
 
 using namespace gan;
@@ -59,11 +91,11 @@ extern "C" int gan_abi_version(void) { return 1; }
 extern "C" size_t gan_conv_workspace_bytes(const gan_conv_geom* g) {
     if (conv_geom_check(g)) return 0;
     const long big_rows = (long)g->n * g->hb * g->wb, small_rows = (long)g->n * g->hs * g->ws;
-    size_t w = max3(igemm_ws_bytes_geom(MODE_FPROP, *g), igemm_ws_bytes_geom(MODE_TPROP, *g),
-                    igemm_ws_bytes_geom(MODE_WGRAD, *g));
     size_t b = colsum_ws_bytes(big_rows, g->cb);
     size_t b2 = colsum_ws_bytes(small_rows, g->cs);
-    return max3(w, b, b2);
+    // the weight gradient keeps its slabs and the bias gradient's partial sums side by side
+    return max3(igemm_ws_bytes_geom(MODE_FPROP, *g), igemm_ws_bytes_geom(MODE_TPROP, *g),
+                align256(igemm_ws_bytes_geom(MODE_WGRAD, *g)) + (b > b2 ? b : b2));
 }
 
 extern "C" int gan_conv2d_fwd(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
@@ -84,11 +116,8 @@ extern "C" int gan_conv2d_wgrad(const gan_conv_geom* g, const float* x, const fl
                                 int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream) {
     if (int rc = conv_geom_check(g)) return rc;
     GAN_CHECK_ARG(x && dy && dw, "gan_conv2d_wgrad: NULL tensor");
-    if (int rc = run_igemm_geom(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, ws_bytes, as_stream(stream),
-                                "gan_conv2d_wgrad"))
-        return rc;
-    if (db) return colsum(dy, db, (long)g->n * g->hs * g->ws, g->cs, accumulate, ws, ws_bytes, as_stream(stream), "gan_conv2d_wgrad");
-    return 0;
+    return wgrad_with_bias(*g, x, dy, dw, db, dy, (long)g->n * g->hs * g->ws, g->cs, accumulate, ws, ws_bytes,
+                           as_stream(stream), "gan_conv2d_wgrad");
 }
 
 extern "C" int gan_deconv2d_fwd(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
@@ -110,11 +139,8 @@ extern "C" int gan_deconv2d_wgrad(const gan_conv_geom* g, const float* x, const 
     if (int rc = conv_geom_check(g)) return rc;
     GAN_CHECK_ARG(x && dy && dw, "gan_deconv2d_wgrad: NULL tensor");
     // dy (big side) plays the conv input, x (small side) the conv output gradient
-    if (int rc = run_igemm_geom(MODE_WGRAD, *g, dy, x, dw, nullptr, accumulate, g->cs, ws, ws_bytes, as_stream(stream),
-                                "gan_deconv2d_wgrad"))
-        return rc;
-    if (db) return colsum(dy, db, (long)g->n * g->hb * g->wb, g->cb, accumulate, ws, ws_bytes, as_stream(stream), "gan_deconv2d_wgrad");
-    return 0;
+    return wgrad_with_bias(*g, dy, x, dw, db, dy, (long)g->n * g->hb * g->wb, g->cb, accumulate, ws, ws_bytes,
+                           as_stream(stream), "gan_deconv2d_wgrad");
 }
 
 // ---------------------------------------------------------------------------- thin linear
@@ -260,11 +286,8 @@ extern "C" int gan_linear_wgrad(int rows, int in_dim, int out_dim, const float* 
                               in_dim, accumulate);
         return check_launch("gan_linear_wgrad");
     }
-    if (int rc = run_igemm_geom(MODE_WGRAD, linear_geom(rows, in_dim, out_dim), x, dy, dmatrix, nullptr, accumulate, out_dim,
-                                ws, ws_bytes, as_stream(stream), "gan_linear_wgrad"))
-        return rc;
-    if (dbias) return colsum(dy, dbias, rows, out_dim, accumulate, ws, ws_bytes, as_stream(stream), "gan_linear_wgrad");
-    return 0;
+    return wgrad_with_bias(linear_geom(rows, in_dim, out_dim), x, dy, dmatrix, dbias, dy, rows, out_dim, accumulate, ws,
+                           ws_bytes, as_stream(stream), "gan_linear_wgrad");
 }
 
 // ---------------------------------------------------------------------------- plan pinning

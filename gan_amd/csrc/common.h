@@ -34,6 +34,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Last stage of a bias-gradient column sum: out[ch] (+)= sum over row blocks of partial[rb][ch], one wave per
+// channel with a fixed shuffle tree.  It depends only on the partial sums, so besides its own launch it can be
+// carried by `blocks` extra workgroups at the end of another launch's grid (the split-K slab reduction of the
+// weight gradient it belongs to).
+struct ColsumFinal {
+    const float* partial;
+    float* out;
+    int c, rblocks, accumulate;
+    int blocks;  // workgroups of 256 threads that cover c channels; 0 = no job
+};
+
+__device__ __forceinline__ void colsum_final_block(const ColsumFinal& j, int block) {
+    const int ch = (block * 256 + (int)threadIdx.x) >> 6;  // one wave per channel
+    const int lane = threadIdx.x & 63;
+    if (ch >= j.c) return;
+    float s = 0.f;
+    for (int rb = lane; rb < j.rblocks; rb += 64) s += j.partial[(long)rb * j.c + ch];
+    s = wave_sum(s);
+    if (lane == 0) j.out[ch] = (j.accumulate ? j.out[ch] : 0.f) + s;
+}
+
 __device__ __forceinline__ float apply_act(float z, int act, float param) {
     switch (act) {
         case GAN_ACT_RELU: return z > 0.f ? z : 0.f;

@@ -300,16 +300,7 @@ __global__ __launch_bounds__(256) void colsum_partial_thin_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int c,
-                                                           int rblocks, int accumulate) {
-    const int ch = (blockIdx.x * 256 + threadIdx.x) >> 6;  // one wave per channel
-    const int lane = threadIdx.x & 63;
-    if (ch >= c) return;
-    float s = 0.f;
-    for (int rb = lane; rb < rblocks; rb += 64) s += partial[(long)rb * c + ch];
-    s = wave_sum(s);
-    if (lane == 0) out[ch] = (accumulate ? out[ch] : 0.f) + s;
-}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const ColsumFinal job) { colsum_final_block(job, blockIdx.x); }
 
 static bool colsum_vec4(int c) { return (c % 4 == 0) && (c / 4 <= 256) && (256 % (c / 4) == 0); }
 
@@ -341,8 +332,9 @@ size_t colsum_ws_bytes(long rows, int c) {
     return (size_t)rb * c * sizeof(float);
 }
 
-int colsum(const float* x, float* out, long rows, int c, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-           const char* what) {
+// First stage: partial[rb][c] into ws.  Fills `job` with what the last stage needs.
+int colsum_partial(const float* x, long rows, int c, void* ws, size_t ws_bytes, hipStream_t st, const char* what,
+                   ColsumFinal* job) {
     int rb;
     long rpb;
     colsum_plan(rows, c, &rb, &rpb);
@@ -360,9 +352,26 @@ int colsum(const float* x, float* out, long rows, int c, int accumulate, void* w
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(rb, (c + 63) / 64), dim3(256), 0, st, x, static_cast<float*>(ws), rows,
                            c, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, st, static_cast<const float*>(ws), out, c, rb,
-                       accumulate);
+    job->partial = static_cast<const float*>(ws);
+    job->c = c;
+    job->rblocks = rb;
+    job->blocks = (c + 3) / 4;
     return check_launch(what);
+}
+
+// Last stage as a launch of its own.
+int colsum_final(const ColsumFinal& job, hipStream_t st, const char* what) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(job.blocks), dim3(256), 0, st, job);
+    return check_launch(what);
+}
+
+int colsum(const float* x, float* out, long rows, int c, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+           const char* what) {
+    ColsumFinal job;
+    if (int rc = colsum_partial(x, rows, c, ws, ws_bytes, st, what, &job)) return rc;
+    job.out = out;
+    job.accumulate = accumulate;
+    return colsum_final(job, st, what);
 }
 
 // ------------------------------------------------------------------ Adam (TensorFlow 1.x form)

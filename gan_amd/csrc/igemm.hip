@@ -509,11 +509,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
 #include "igemm_split.h"
 
-// out[i] = (accumulate ? out[i] : 0) + bias[i % c] + sum_s slab[s][i]
+// out[i] = (accumulate ? out[i] : 0) + bias[i % c] + sum_s slab[s][i].  The first `own_blocks` workgroups do
+// that; any further ones carry the last stage of the bias-gradient column sum (`tail`).
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                     const float* __restrict__ bias, long elems, int c, int splits,
-                                    int accumulate) {
-    const long stride = (long)gridDim.x * blockDim.x;
+                                    int accumulate, int own_blocks, const ColsumFinal tail) {
+    if ((int)blockIdx.x >= own_blocks) {
+        colsum_final_block(tail, blockIdx.x - own_blocks);
+        return;
+    }
+    const long stride = (long)own_blocks * blockDim.x;
     if ((elems & 3) == 0 && (c & 3) == 0) {
         const long n4 = elems >> 2;
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -548,8 +553,13 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 // and the 16 partial sums are combined through LDS in a fixed order.  Needs elems % 4 == 0.
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 const float* __restrict__ bias, long elems, int c,
-                                                                int splits, int accumulate) {
+                                                                int splits, int accumulate, int own_blocks,
+                                                                const ColsumFinal tail) {
     __shared__ float4 red[16][16];
+    if ((int)blockIdx.x >= own_blocks) {          // (uniform per workgroup: no barrier is skipped by part of one)
+        colsum_final_block(tail, blockIdx.x - own_blocks);
+        return;
+    }
     const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long i4 = (long)blockIdx.x * 16 + col;
     const long n4 = elems >> 2;
@@ -930,7 +940,12 @@ static size_t plan_ws_bytes(const Plan& pl) {
 }
 
 // Runs one contraction.  `out_c` is the channel count of the output's last axis (bias period).
-int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what) {
+// `tail` (optional): a pending column-sum last stage; if the contraction has a slab reduction launch, that launch
+// carries it and *tail_done is set.
+int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
+              const ColsumFinal* tail = nullptr, int* tail_done = nullptr) {
+    ColsumFinal job = ColsumFinal{nullptr, nullptr, 0, 0, 0, 0};
+    if (tail != nullptr && tail_done != nullptr && tail->blocks > 0) job = *tail;
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
     if (mode == MODE_TPROP && thin_tprop_ok(a)) return run_thin_tprop(a, s, what);
@@ -963,17 +978,20 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     if (int rc = check_launch(what)) return rc;
     if (pl.splits >= 16 && (pl.out_elems & 3) == 0) {
         const long n4 = pl.out_elems >> 2;
-        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s,
-                           static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate);
+        const int own = (int)((n4 + 15) / 16);
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)(own + job.blocks)), dim3(256), 0, s,
+                           static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, own, job);
         if (int rc = check_launch(what)) return rc;
+        if (job.blocks > 0) *tail_done = 1;
     } else if (pl.splits > 1) {
         long work = (pl.out_elems + 3) / 4;
         int blocks = (int)((work + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(ws),
-                           final_out, bias, pl.out_elems, out_c, pl.splits, accumulate);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks + job.blocks), dim3(256), 0, s, static_cast<const float*>(ws),
+                           final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, blocks, job);
         if (int rc = check_launch(what)) return rc;
+        if (job.blocks > 0) *tail_done = 1;
     }
     return 0;
 }
@@ -1052,8 +1070,9 @@ size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g) {
 }
 
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
-                   int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what) {
-    return run_igemm(mode, make_args(mode, g, a, b, out, bias, accumulate), out_c, ws, ws_bytes, s, what);
+                   int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
+                   const ColsumFinal* tail, int* tail_done) {
+    return run_igemm(mode, make_args(mode, g, a, b, out, bias, accumulate), out_c, ws, ws_bytes, s, what, tail, tail_done);
 }
 
 }  // namespace gan

@@ -207,7 +207,9 @@ int gan_get_exact_f32(void);
  *   GAN_HIP_FORCE_CFG=<0..6>, GAN_HIP_FORCE_SPLITS=<n>  override the plan of every contraction;
  *   GAN_HIP_NO_THIN=1         keeps thin outputs (<= 4 channels / <= 4 linear outputs) on the MFMA path;
  *   GAN_HIP_SLOW_GATHER=1     general gather arithmetic in the split kernel (results are bit-identical);
- *   GAN_HIP_SCALAR_EPILOGUE=1 dword stores instead of the 16-byte epilogue. */
+ *   GAN_HIP_SCALAR_EPILOGUE=1 dword stores instead of the 16-byte epilogue;
+ *   GAN_HIP_SEPARATE_COLSUM=1 bias gradients as two launches after the weight gradient instead of one before it
+ *                             and a last stage carried by the slab reduction's launch (results are bit-identical). */
 
 /* ---- utilities ------------------------------------------------------------------------- */
 int gan_fill(float* x, long n, float value, gan_stream_t stream);

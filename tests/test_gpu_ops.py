@@ -527,6 +527,45 @@ def test_split_kernel_gather_variants_agree_bitwise(L, case, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case,accumulate", [((4, 16, 16, 64, 128, 5, 2), 0), ((2, 12, 12, 3, 16, 5, 2), 1),
+                                             ((64, 8, 8, 16, 10, 3, 1), 0)])
+def test_bias_gradient_carried_by_the_slab_reduction_is_bit_identical(L, case, accumulate, monkeypatch):
+    """Weight gradient + bias gradient: the column sum's first stage runs ahead of the contraction and its last
+    stage rides on the slab reduction's launch; as launches of their own (the test knob) the same numbers come
+    out, for conv, transposed conv and linear, overwriting or accumulating."""
+    from gpu_util import geom_for
+    n, h, w, cb, cs, k, s = case
+    g = geom_for(n, h, w, cb, cs, k, s, 'SAME')
+    gp = ctypes.byref(g)
+    x = torch.randn(n, h, w, cb, device='cuda')
+    dy = torch.randn(n, g.hs, g.ws, cs, device='cuda')
+    xl, dyl = torch.randn(n * 8, 96, device='cuda'), torch.randn(n * 8, 40, device='cuda')
+    outs = []
+    for separate in (False, True):
+        if separate:
+            monkeypatch.setenv("GAN_HIP_SEPARATE_COLSUM", "1")
+        torch.manual_seed(3)
+        dw, db = torch.randn(k, k, cb, cs, device='cuda'), torch.randn(cs, device='cuda')       # accumulate onto these
+        dwt, dbt = torch.randn(k, k, cb, cs, device='cuda'), torch.randn(cb, device='cuda')
+        dm, dbl = torch.randn(96, 40, device='cuda'), torch.randn(40, device='cuda')
+        wp, wn = _ws(L, g)
+        st = L.stream()
+        L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), accumulate, wp, wn, st))
+        # transposed conv: x is the small tensor, dy the big one, the bias has cb entries
+        L.check(L.lib.gan_deconv2d_wgrad(gp, L.ptr(dy), L.ptr(x), L.ptr(dwt), L.ptr(dbt), accumulate, wp, wn, st))
+        nb = int(L.lib.gan_linear_workspace_bytes(n * 8, 96, 40))
+        lp, ln = L.workspace(nb)
+        L.check(L.lib.gan_linear_wgrad(n * 8, 96, 40, L.ptr(xl), L.ptr(dyl), L.ptr(dm), L.ptr(dbl), accumulate, lp, ln, st))
+        torch.cuda.synchronize()
+        outs.append((dw, db, dwt, dbt, dm, dbl))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and the bias gradients are the column sums
+    if not accumulate:
+        torch.testing.assert_close(outs[0][1].double(), dy.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(outs[0][3].double(), x.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-4)
+
+
 def test_split_bf16_arithmetic_is_as_accurate_as_the_fp32_mfma(L):
     """The default contraction arithmetic (fp32 operands split exactly into three bf16 parts, six
     part products on the bf16 matrix pipe, fp32 accumulation) against the float64 oracle, next to
