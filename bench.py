@@ -164,6 +164,7 @@ def cpu_baseline(iters):
 
 
 def main():
+    global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -178,8 +179,12 @@ def main():
                     help="collective backend; gloo only for rehearsing several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--exact-f32", action="store_true",
                     help="keep every contraction on the fp32 MFMA instead of the bf16 MFMA on split fp32 operands")
+    ap.add_argument("--batch", type=int, default=BATCH,
+                    help="images per GPU per step; 64 is the benchmark's configuration, other values are for exploration "
+                         "and are named in config.workload")
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
     args = ap.parse_args()
+    nominal_batch, BATCH = BATCH, args.batch
 
     # Libraries underneath (RCCL's version banner) write to stdout; the contract is ONE JSON line
     # there, so everything before the final print goes to stderr instead.
@@ -295,7 +300,8 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DCGAN 64x64x3 CelebA-shaped synthetic images, batch 64 per GPU, fp32, "
+            "config": {"workload": "DCGAN 64x64x3 CelebA-shaped synthetic images, batch %d per GPU%s, fp32, "
+                                   % (BATCH, "" if BATCH == nominal_batch else " (NOT the benchmark's batch of %d)" % nominal_batch) +
                                    "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 and pg is None
