@@ -387,6 +387,200 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// ---------------------------------------------------------------------------- one-launch path
+// Small activations (rows <= 1024 per group, c % 4 == 0: the 4x4 layers of the 64x64 networks, the 2-D batch
+// norms after linear layers).  The three-launch path above costs 8-11 us however small the tensor is, because
+// each launch is a chain of dependent memory round trips.  Here one workgroup owns FOUR channels of one
+// group outright: thread t holds rows t, t+256, ... of those channels in registers (one float4 per row), the
+// statistics are exact two-pass sums reduced inside the workgroup (shuffle tree + 4 wave partials in LDS, fixed
+// order), and the normalised rows are written from the registers: one read, one write, one launch
+// (rows 64 / 1024: 3.4 / 5.2 us forward, 4.1 / 8.3 us backward against 7.5 / 8.5 and 9.3 / 10.8).
+// A workgroup uses 16 bytes of every 128-byte line it pulls into its CU, which is why this stops paying
+// above ~1024 rows (4096 rows: 25 us backward against 12), and the backward pass, whose one workgroup per quad
+// must see every group for dgamma / dbeta, keeps the three launches when groups are stacked.
+// A 128-byte line holds 8 neighbouring channel quads, so the quads are dealt to workgroups such that the 8
+// workgroups sharing a line have ids 8 apart: with workgroups assigned to the 8 XCDs round robin they sit on
+// the same XCD and the line crosses the fabric once.
+constexpr int kFusedMaxRows = 1024;
+
+__device__ __forceinline__ int fused_quad(int block, int nquads) {
+    return (nquads % 8 == 0) ? (block % 8) * (nquads / 8) + block / 8 : block;
+}
+
+// sum over the 256 threads of the workgroup, result in every thread; `red` is 4 float4 of LDS
+__device__ __forceinline__ float4 block_sum4(float4 v, float4* red) {
+    v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);
+    __syncthreads();                        // the previous use of `red` is over
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return f4_add(f4_add(red[0], red[1]), f4_add(red[2], red[3]));
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ moving_mean,
+                                                           float* __restrict__ moving_var, const float* __restrict__ residual,
+                                                           float* __restrict__ y, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd, int groups, int rows, int c, float eps,
+                                                           float momentum, int unbiased, int act, float act_param,
+                                                           int all_groups) {
+    __shared__ float4 red[4];
+    const int c4 = c >> 2;
+    const int q = fused_quad(blockIdx.x, c4);
+    const int g0 = all_groups ? 0 : blockIdx.y, g1 = all_groups ? groups : g0 + 1;
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[q], be = reinterpret_cast<const float4*>(beta)[q];
+    float4 mm = make_float4(0.f, 0.f, 0.f, 0.f), mv = mm;
+    if (moving_mean != nullptr) {
+        mm = reinterpret_cast<const float4*>(moving_mean)[q];
+        mv = reinterpret_cast<const float4*>(moving_var)[q];
+    }
+    const float n = (float)rows, inv_n = 1.0f / n;
+    for (int grp = g0; grp < g1; ++grp) {
+        const long base = (long)grp * rows * c4 + q;
+        const float4* xp = reinterpret_cast<const float4*>(x) + base;
+        float4 v[RPT];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = threadIdx.x + 256 * i;
+            v[i] = (r < rows) ? xp[(long)r * c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s = f4_add(s, v[i]);
+        }
+        s = block_sum4(s, red);
+        const float4 mean = make_float4(s.x * inv_n, s.y * inv_n, s.z * inv_n, s.w * inv_n);
+        float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            if (threadIdx.x + 256 * i < rows) {
+                const float4 d = f4_sub(v[i], mean);
+                m2 = f4_fma(d, d, m2);
+            }
+        }
+        m2 = block_sum4(m2, red);
+        const float4 var = make_float4(m2.x * inv_n, m2.y * inv_n, m2.z * inv_n, m2.w * inv_n);
+        const float4 rstd = make_float4(1.0f / sqrtf(var.x + eps), 1.0f / sqrtf(var.y + eps), 1.0f / sqrtf(var.z + eps),
+                                        1.0f / sqrtf(var.w + eps));
+        if (threadIdx.x == 0) {
+            reinterpret_cast<float4*>(save_mean + (long)grp * c)[q] = mean;
+            reinterpret_cast<float4*>(save_rstd + (long)grp * c)[q] = rstd;
+        }
+        const float corr = unbiased ? n / fmaxf(n - 1.f, 1.f) : 1.f;
+        const float keep = momentum, take = 1.f - momentum;
+        mm = make_float4(mm.x * keep + mean.x * take, mm.y * keep + mean.y * take, mm.z * keep + mean.z * take,
+                         mm.w * keep + mean.w * take);
+        mv = make_float4(mv.x * keep + var.x * corr * take, mv.y * keep + var.y * corr * take,
+                         mv.z * keep + var.z * corr * take, mv.w * keep + var.w * corr * take);
+        float4* yp = reinterpret_cast<float4*>(y) + base;
+        const float4* rp = residual ? reinterpret_cast<const float4*>(residual) + base : nullptr;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = threadIdx.x + 256 * i;
+            if (r < rows) {
+                float4 o;
+                o.x = apply_act((v[i].x - mean.x) * rstd.x * ga.x + be.x, act, act_param);
+                o.y = apply_act((v[i].y - mean.y) * rstd.y * ga.y + be.y, act, act_param);
+                o.z = apply_act((v[i].z - mean.z) * rstd.z * ga.z + be.z, act, act_param);
+                o.w = apply_act((v[i].w - mean.w) * rstd.w * ga.w + be.w, act, act_param);
+                if (rp) o = f4_add(o, rp[(long)r * c4]);
+                yp[(long)r * c4] = o;
+            }
+        }
+    }
+    if (moving_mean != nullptr && threadIdx.x == 0) {
+        reinterpret_cast<float4*>(moving_mean)[q] = mm;
+        reinterpret_cast<float4*>(moving_var)[q] = mv;
+    }
+}
+
+// One workgroup per channel quad takes every group in turn: dgamma / dbeta are sums over the groups.
+template <int RPT>
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate, int groups, int rows, int c,
+                                                           int act, float act_param) {
+    __shared__ float4 red[4];
+    const int c4 = c >> 2;
+    const int q = fused_quad(blockIdx.x, c4);
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[q], be = reinterpret_cast<const float4*>(beta)[q];
+    const float inv_rows = 1.0f / (float)rows;
+    float4 tg = make_float4(0.f, 0.f, 0.f, 0.f), tb = tg;
+    for (int grp = 0; grp < groups; ++grp) {
+        const long base = (long)grp * rows * c4 + q;
+        const float4* xp = reinterpret_cast<const float4*>(x) + base;
+        const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+        const float4 mu = reinterpret_cast<const float4*>(mean + (long)grp * c)[q];
+        const float4 rs = reinterpret_cast<const float4*>(rstd + (long)grp * c)[q];
+        float4 xv[RPT], dv[RPT];
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = threadIdx.x + 256 * i;
+            if (r < rows) {
+                xv[i] = xp[(long)r * c4];
+                dv[i] = dp[(long)r * c4];
+                float4 xh, dz;
+                dz.x = dz_of(xv[i].x, dv[i].x, mu.x, rs.x, ga.x, be.x, act, act_param, xh.x);
+                dz.y = dz_of(xv[i].y, dv[i].y, mu.y, rs.y, ga.y, be.y, act, act_param, xh.y);
+                dz.z = dz_of(xv[i].z, dv[i].z, mu.z, rs.z, ga.z, be.z, act, act_param, xh.z);
+                dz.w = dz_of(xv[i].w, dv[i].w, mu.w, rs.w, ga.w, be.w, act, act_param, xh.w);
+                s0 = f4_add(s0, dz);
+                s1 = f4_fma(dz, xh, s1);
+            } else {
+                xv[i] = dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        s0 = block_sum4(s0, red);
+        s1 = block_sum4(s1, red);
+        tb = f4_add(tb, s0);
+        tg = f4_add(tg, s1);
+        if (dx != nullptr) {
+            float4* op = reinterpret_cast<float4*>(dx) + base;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = threadIdx.x + 256 * i;
+                if (r < rows) {
+                    float xh;
+                    float4 o;
+                    float dz = dz_of(xv[i].x, dv[i].x, mu.x, rs.x, ga.x, be.x, act, act_param, xh);
+                    o.x = ga.x * rs.x * (dz - s0.x * inv_rows - xh * (s1.x * inv_rows));
+                    dz = dz_of(xv[i].y, dv[i].y, mu.y, rs.y, ga.y, be.y, act, act_param, xh);
+                    o.y = ga.y * rs.y * (dz - s0.y * inv_rows - xh * (s1.y * inv_rows));
+                    dz = dz_of(xv[i].z, dv[i].z, mu.z, rs.z, ga.z, be.z, act, act_param, xh);
+                    o.z = ga.z * rs.z * (dz - s0.z * inv_rows - xh * (s1.z * inv_rows));
+                    dz = dz_of(xv[i].w, dv[i].w, mu.w, rs.w, ga.w, be.w, act, act_param, xh);
+                    o.w = ga.w * rs.w * (dz - s0.w * inv_rows - xh * (s1.w * inv_rows));
+                    op[(long)r * c4] = o;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (dgamma) {
+            float4 o = accumulate ? reinterpret_cast<const float4*>(dgamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(dgamma)[q] = f4_add(o, tg);
+        }
+        if (dbeta) {
+            float4 o = accumulate ? reinterpret_cast<const float4*>(dbeta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(dbeta)[q] = f4_add(o, tb);
+        }
+    }
+}
+
+static bool fused_bn_ok(int rows, int c, const void* p0, const void* p1, const void* p2, const void* p3) {
+    auto a16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return rows <= kFusedMaxRows && (c & 3) == 0 && a16(p0) && a16(p1) && a16(p2) && a16(p3) &&
+           !getenv("GAN_HIP_THREE_LAUNCH_BN");
+}
+
+#define GAN_FUSED_BN_DISPATCH(KERNEL, rows, GRID, st, ...)                                            \
+    do {                                                                                              \
+        if ((rows) <= 256) hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, st, __VA_ARGS__);        \
+        else if ((rows) <= 512) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, st, __VA_ARGS__);                      \
+    } while (0)
+
 static int grid_for(long work_items) {
     long b = (work_items + 255) / 256;
     if (b > 2048) b = 2048;
@@ -428,6 +622,15 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     GAN_CHECK_ARG(ws && ws_bytes >= need, "gan_bn_fwd_train: workspace of %zu bytes needed, %zu given", need, ws_bytes);
     const BnShape s = bn_shape(groups, rows, c);
     hipStream_t st = as_stream(stream);
+    if (fused_bn_ok(rows, c, x, y, residual, save_mean) && fused_bn_ok(rows, c, save_rstd, gamma, beta, moving_mean) &&
+        fused_bn_ok(rows, c, moving_var, nullptr, nullptr, nullptr)) {
+        // stacked passes move the averages once per group, in order: one workgroup takes the groups in turn
+        const int all_groups = (moving_mean != nullptr && groups > 1) ? 1 : 0;
+        GAN_FUSED_BN_DISPATCH(bn_fwd_fused_kernel, rows, dim3(c / 4, all_groups ? 1 : groups), st, x, gamma, beta, moving_mean,
+                              moving_var, residual, y, save_mean, save_rstd, groups, rows, c, eps, momentum,
+                              unbiased_moving_var, act, act_param, all_groups);
+        return check_launch("gan_bn_fwd_train");
+    }
     float2* partial = static_cast<float2*>(ws);
     if (s.vec4)
         hipLaunchKernelGGL(bn_partial_stats_v4_kernel, dim3(s.rblocks, groups), dim3(256), 0, st, x, partial, s);
@@ -492,6 +695,12 @@ extern "C" int gan_bn_bwd(const float* x, const float* gamma, const float* beta,
     GAN_CHECK_ARG(ws && ws_bytes >= need, "gan_bn_bwd: workspace of %zu bytes needed, %zu given", need, ws_bytes);
     const BnShape s = bn_shape(groups, rows, c);
     hipStream_t st = as_stream(stream);
+    if (groups == 1 && fused_bn_ok(rows, c, x, dy, dx, save_mean) && fused_bn_ok(rows, c, save_rstd, gamma, beta, dgamma) &&
+        fused_bn_ok(rows, c, dbeta, nullptr, nullptr, nullptr)) {
+        GAN_FUSED_BN_DISPATCH(bn_bwd_fused_kernel, rows, dim3(c / 4), st, x, gamma, beta, save_mean, save_rstd, dy, dx, dgamma,
+                              dbeta, accumulate, groups, rows, c, act, act_param);
+        return check_launch("gan_bn_bwd");
+    }
     float2* partial = static_cast<float2*>(ws);
     float2* sums = partial + (size_t)groups * s.rblocks * c;
     if (s.vec4)

@@ -208,6 +208,7 @@ int gan_get_exact_f32(void);
  *   GAN_HIP_NO_THIN=1         keeps thin outputs (<= 4 channels / <= 4 linear outputs) on the MFMA path;
  *   GAN_HIP_SLOW_GATHER=1     general gather arithmetic in the split kernel (results are bit-identical);
  *   GAN_HIP_SCALAR_EPILOGUE=1 dword stores instead of the 16-byte epilogue;
+ *   GAN_HIP_THREE_LAUNCH_BN=1 keeps small batch norms (<= 1024 rows per group) on the general three-launch path;
  *   GAN_HIP_SEPARATE_COLSUM=1 bias gradients as two launches after the weight gradient instead of one before it
  *                             and a last stage carried by the slab reduction's launch (results are bit-identical). */
 

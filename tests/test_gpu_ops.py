@@ -331,6 +331,35 @@ def test_batch_norm_train(L, shape, groups, act, param):
         assert_close(host(ye), _act_ref(ze, act, param), "bn eval")
 
 
+@pytest.mark.parametrize("groups,rows,c", [(1, 1024, 512), (2, 1024, 512), (1, 64, 1024), (3, 300, 8), (1, 513, 132)])
+def test_one_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows, c, monkeypatch):
+    """Small batch norms (<= 1024 rows per group) run as ONE launch, a workgroup per channel quad with the
+    rows in registers; the general three-launch path (test knob) gives the same results to rounding,
+    moving averages of stacked passes included."""
+    torch.manual_seed(groups * 1000 + rows)
+    x = torch.randn(groups * rows, c, device='cuda') * 1.5 + 0.3
+    res, dy = torch.randn_like(x), torch.randn_like(x)
+    ga, be = torch.randn(c, device='cuda') * 0.3 + 1, torch.randn(c, device='cuda') * 0.3
+    outs = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("GAN_HIP_THREE_LAUNCH_BN", "1")
+        mm, mv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        sm, sr = torch.empty(groups * c, device='cuda'), torch.empty(groups * c, device='cuda')
+        dg, db = torch.ones(c, device='cuda'), torch.ones(c, device='cuda')
+        wp, wn = L.workspace(int(L.lib.gan_bn_workspace_bytes(groups, rows, c)))
+        st = L.stream()
+        L.check(L.lib.gan_bn_fwd_train(L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(mm), L.ptr(mv), L.ptr(res), L.ptr(y), L.ptr(sm),
+                                       L.ptr(sr), groups, rows, c, 1e-5, 0.9, 1, 3, 0.0, wp, wn, st))
+        L.check(L.lib.gan_bn_bwd(L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(sm), L.ptr(sr), L.ptr(dy), L.ptr(dx), L.ptr(dg),
+                                 L.ptr(db), 1, groups, rows, c, 3, 0.0, wp, wn, st))
+        torch.cuda.synchronize()
+        outs.append((y, sm, sr, mm, mv, dx, dg, db))
+    for name, a, b in zip(("y", "mean", "rstd", "moving mean", "moving variance", "dx", "dgamma", "dbeta"), *outs):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()), msg=lambda m, n=name: n + ": " + m)
+
+
 def test_batch_norm_unbiased_moving_variance_flag(L):
     from gpu_util import assert_close, dev, host
     shape, c = (8, 4, 4, 16), 16
