@@ -18,87 +18,50 @@ import numpy as np
 
 
 def str2bool(v):
-    if v.lower() in ('yes', 'true', 't', 'y', '1'):
+    """main.py:18-24: yes/true/t/y/1 and no/false/f/n/0, any case."""
+    word = v.lower()
+    if word in ('yes', 'true', 't', 'y', '1'):
         return True
-    elif v.lower() in ('no', 'false', 'f', 'n', '0'):
+    if word in ('no', 'false', 'f', 'n', '0'):
         return False
-    else:
-        raise argparse.ArgumentTypeError('Boolean value expected.')
+    raise argparse.ArgumentTypeError('Boolean value expected.')
+
+
+# The reference's flag surface (main.py:104-188) as a table: name, type, default.  `bool` stands for str2bool.
+# Flags in the second table only feed models outside the hot path; they are accepted so that existing command
+# lines keep parsing.
+REFERENCE_FLAGS = [
+    ('model', str, 'DCGAN'), ('nEpochs', int, 25), ('save_every_batch', int, 50), ('print_every', int, 1),
+    ('batch_size', int, 64), ('train_size', int, 1e8), ('load_size', int, 286), ('fine_size', int, 256),
+    ('ngf', int, 32), ('ndf', int, 64), ('input_nc', int, 3), ('output_nc', int, 3), ('niter', int, 200),
+    ('lr', float, 0.0002), ('beta1', float, 0.5), ('flip', bool, True), ('which_direction', str, 'AtoB'),
+    ('phase', str, 'train'), ('save_latest_freq', int, 5000), ('continue_train', bool, False),
+    ('serial_batches', bool, False), ('serial_batch_iter', bool, True), ('checkpoint_dir', str, './checkpoint'),
+    ('sample_dir', str, './samples'), ('test_dir', str, './test'), ('L1_lambda', float, 10.0),
+    ('use_resnet', bool, True), ('use_lsgan', bool, True), ('max_size', int, 50),
+    ('z_dim', int, 100), ('t_dim', int, 256), ('gf_dim', int, 64), ('df_dim', int, 64), ('gfc_dim', int, 1024),
+    ('dfc_dim', int, 1024), ('caption_vector_length', int, None), ('resume_model', str, None),
+    ('input_height', int, 108), ('input_width', int, None), ('output_height', int, 64), ('output_width', int, None),
+    ('dataset', str, 'mnist'), ('data_dir', str, 'data'), ('log_dir', str, 'logs'),
+    ('input_fname_pattern', str, '*.jpg'), ('crop', bool, True), ('visualize', bool, False), ('note', str, ''),
+    ('textEncoder', str, 'skipthought'),
+]
+OUT_OF_PATH_FLAGS = [
+    ('gru_num_units', int, 512), ('gru_num_layers', int, 2), ('sequence_length', int, 30),
+    ('dropout_keep_prob', float, 0.5), ('decay_every_nEpochs', int, 8), ('decay_factor', float, 0.5),
+    ('values_per_input_shard', int, 2300), ('input_queue_capacity_factor', int, 2),
+    ('num_input_reader_threads', int, 1), ('num_preprocess_threads', int, 4),
+    ('inception_checkpoint_file', str, 'checkpoint/inception_v3.ckpt'), ('vocab_file', str, 'vocab.txt'),
+    ('num_lstm_units', int, 1024), ('embedding_size', int, 1024), ('image_size', int, 64), ('vocab_size', int, 2500),
+    ('use_TextNLL', bool, True), ('use_CaptionNLL', bool, True), ('use_GAN', bool, True), ('use_wrongImage', bool, True),
+]
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description='')
-    parser.add_argument('--model', default='DCGAN', help='model to use [DCGAN, Text2Image, CycleGAN]')
-    parser.add_argument('--nEpochs', type=int, default=25, help='# of epoch')
-    parser.add_argument('--save_every_batch', type=int, default=50,
-                        help='Save Model/Samples every x iterations over batches(does not overwrite previously saved models)')
-    parser.add_argument('--print_every', type=int, default=1,
-                        help='print the debug information every print_freq iterations')
-    parser.add_argument('--batch_size', type=int, default=64, help='# images in batch')
-    parser.add_argument('--train_size', type=int, default=1e8, help='# images used to train')
-    parser.add_argument('--load_size', type=int, default=286, help='scale images to this size')
-    parser.add_argument('--fine_size', type=int, default=256, help='then crop to this size')
-    parser.add_argument('--ngf', type=int, default=32, help='# of gen filters in first conv layer')
-    parser.add_argument('--ndf', type=int, default=64, help='# of discri filters in first conv layer')
-    parser.add_argument('--input_nc', type=int, default=3, help='# of input image channels')
-    parser.add_argument('--output_nc', type=int, default=3, help='# of output image channels')
-    parser.add_argument('--niter', type=int, default=200, help='# of iter at starting learning rate')
-    parser.add_argument('--lr', type=float, default=0.0002, help='initial learning rate for adam')
-    parser.add_argument('--beta1', type=float, default=0.5, help='momentum term of adam')
-    parser.add_argument('--flip', type=str2bool, default=True, help='if flip the images for data argumentation')
-    parser.add_argument('--which_direction', default='AtoB', help='AtoB or BtoA')
-    parser.add_argument('--phase', default='train', help='train, valid, test')
-    parser.add_argument('--save_latest_freq', type=int, default=5000,
-                        help='save the latest model every latest_freq sgd iterations (overwrites the previous latest model)')
-    parser.add_argument('--continue_train', type=str2bool, default=False,
-                        help='if continue training, load the latest model: 1: true, 0: false')
-    parser.add_argument('--serial_batches', type=str2bool, default=False,
-                        help='f 1, takes images in order to make batches, otherwise takes them randomly')
-    parser.add_argument('--serial_batch_iter', type=str2bool, default=True, help='iter into serial image list')
-    parser.add_argument('--checkpoint_dir', default='./checkpoint', help='models are saved here')
-    parser.add_argument('--sample_dir', default='./samples', help='sample are saved here')
-    parser.add_argument('--test_dir', default='./test', help='test sample are saved here')
-    parser.add_argument('--L1_lambda', type=float, default=10.0, help='weight on L1 term in objective')
-    parser.add_argument('--use_resnet', type=str2bool, default=True, help='generation network using reidule block')
-    parser.add_argument('--use_lsgan', type=str2bool, default=True, help='gan loss defined in lsgan')
-    parser.add_argument('--max_size', type=int, default=50,
-                        help='max size of image pool, 0 means do not use image pool')
-
-    parser.add_argument('--z_dim', type=int, default=100, help="Noise Dimension")
-    parser.add_argument('--t_dim', type=int, default=256, help='Text feature dimension')
-    parser.add_argument('--gf_dim', type=int, default=64, help='Number of conv in the first layer gen.')
-    parser.add_argument('--df_dim', type=int, default=64, help='Number of conv in the first layer discr.')
-    parser.add_argument('--gfc_dim', type=int, default=1024, help='Dimension of gen untis for fully connected layer [1024]')
-    parser.add_argument('--dfc_dim', type=int, default=1024, help='Dimension of discrim untis for for fully connected layer [1024]')
-    parser.add_argument('--caption_vector_length', type=int, default=None, help='Caption Vector Length')
-    parser.add_argument('--resume_model', type=str, default=None, help='Pre-Trained Model Path, to resume from')
-    parser.add_argument('--input_height', type=int, default=108, help="The size of image to use (will be center cropped)")
-    parser.add_argument('--input_width', type=int, default=None,
-                        help="The size of image to use (will be center cropped), None=input_height")
-    parser.add_argument('--output_height', type=int, default=64, help="The size of output image to produce")
-    parser.add_argument('--output_width', type=int, default=None, help="The size of output image to produce , None=output_height")
-    parser.add_argument('--dataset', default='mnist', help="The name of dataset [celebA, mnist, lsun, horse2zebra, mscoco, flowers]")
-    parser.add_argument('--data_dir', type=str, default="data", help='Data Directory')
-    parser.add_argument('--log_dir', type=str, default="logs", help='tf.Summary Directory')
-    parser.add_argument('--input_fname_pattern', default='*.jpg', help="Glob pattern of filename of input images [*]")
-    parser.add_argument('--crop', type=str2bool, default=True, help="True for training, False for testing [False]")
-    parser.add_argument('--visualize', type=str2bool, default=False, help="True for visualizing, False for nothing [False]")
-    parser.add_argument('--note', type=str, default='', help="")
-
-    parser.add_argument('--textEncoder', type=str, default='skipthought', help="skipthought / DSSJE")
-
-    # flags of models outside the hot path: accepted so that existing command lines keep parsing
-    for name, typ, default in [('gru_num_units', int, 512), ('gru_num_layers', int, 2), ('sequence_length', int, 30),
-                               ('dropout_keep_prob', float, 0.5), ('decay_every_nEpochs', int, 8),
-                               ('decay_factor', float, 0.5), ('values_per_input_shard', int, 2300),
-                               ('input_queue_capacity_factor', int, 2), ('num_input_reader_threads', int, 1),
-                               ('num_preprocess_threads', int, 4),
-                               ('inception_checkpoint_file', str, 'checkpoint/inception_v3.ckpt'),
-                               ('vocab_file', str, 'vocab.txt'), ('num_lstm_units', int, 1024),
-                               ('embedding_size', int, 1024), ('image_size', int, 64), ('vocab_size', int, 2500)]:
-        parser.add_argument('--' + name, type=typ, default=default, help="")
-    for name in ('use_TextNLL', 'use_CaptionNLL', 'use_GAN', 'use_wrongImage'):
-        parser.add_argument('--' + name, type=str2bool, default=True, help="")
+    parser = argparse.ArgumentParser(description='GAN training on MI355X with the flags of the reference\'s main.py')
+    for name, typ, default in REFERENCE_FLAGS + OUT_OF_PATH_FLAGS:
+        parser.add_argument('--' + name, type=str2bool if typ is bool else typ, default=default,
+                            help='as in the reference (default %r)' % (default,))
 
     # extensions
     parser.add_argument('--synthetic_iters', type=int, default=0,
