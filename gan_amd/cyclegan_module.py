@@ -16,7 +16,7 @@ from .ops import batch_norm, conv2d, deconv2d, lrelu
 
 def discriminator(image, options, reuse=False, name="discriminator"):
     with ops.variable_scope(name) as scope:
-        # image is 256 x 256 x input_c_dim
+        # input: [n, 256, 256, input_c_dim] at the reference's sizes
         if reuse:
             scope.reuse_variables()
 
@@ -25,15 +25,15 @@ def discriminator(image, options, reuse=False, name="discriminator"):
         d_bn3 = batch_norm(name='d_bn3')
 
         h0 = lrelu(conv2d(image, options.df_dim, name='d_h0_conv'))
-        # h0 is (128 x 128 x self.df_dim)
+        # -> [n, 128, 128, df_dim]
         h1 = d_bn1(conv2d(h0, options.df_dim * 2, name='d_h1_conv'), act='lrelu')
-        # h1 is (64 x 64 x self.df_dim*2)
+        # -> [n, 64, 64, 2 df_dim]
         h2 = d_bn2(conv2d(h1, options.df_dim * 4, name='d_h2_conv'), act='lrelu')
-        # h2 is (32x 32 x self.df_dim*4)
+        # -> [n, 32, 32, 4 df_dim]
         h3 = d_bn3(conv2d(h2, options.df_dim * 8, d_h=1, d_w=1, name='d_h3_conv'), act='lrelu')
-        # h3 is (32 x 32 x self.df_dim*8)
+        # -> [n, 32, 32, 8 df_dim] (stride 1)
         h4 = conv2d(h3, 1, d_h=1, d_w=1, name='d_h3_pred')
-        # h4 is (32 x 32 x 1)
+        # -> [n, 32, 32, 1]: one logit per patch
         return h4
 
 
@@ -45,7 +45,7 @@ def generator_unet(image, options, reuse=False, name="generator"):
 
 def generator_resnet(image, options, reuse=False, name="generator"):
     with ops.variable_scope(name) as scope:
-        # image is 256 x 256 x input_c_dim
+        # input: [n, 256, 256, input_c_dim] at the reference's sizes
         if reuse:
             scope.reuse_variables()
 
@@ -69,13 +69,13 @@ def generator_resnet(image, options, reuse=False, name="generator"):
 
         s = options.image_size
         s2 = int(s / 2)
-        # Justin Johnson's model from https://github.com/jcjohnson/fast-neural-style/
-        # c7s1-32, d64, d128, R128 x9, u64, u32, c7s1-3
+        # the fast-neural-style layout the reference cites (cyclegan_module.py:121-122): 7x7 stem, two stride-2
+        # convs down, nine residual blocks, two stride-2 transposed convs up, 7x7 head
         c0 = ops.reflect_pad(image, 3)
         c1 = g_e1_bn(conv2d(c0, options.gf_dim, 7, 7, 1, 1, padding='VALID', name='g_e1_c'), act='relu')
         c2 = g_e2_bn(conv2d(c1, options.gf_dim * 2, 3, 3, 2, 2, name='g_e2_c'), act='relu')
         c3 = g_e3_bn(conv2d(c2, options.gf_dim * 4, 3, 3, 2, 2, name='g_e3_c'), act='relu')
-        # define G network with 9 resnet blocks
+        # nine residual blocks
         r = c3
         for i in range(1, 10):
             r = residule_block(r, options.gf_dim * 4, name='g_r%d' % i)
