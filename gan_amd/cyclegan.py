@@ -50,27 +50,16 @@ class ImagePool(object):
 class CycleGAN(object):
     def __init__(self, sess, opts, store=None, world_size=1, process_group=None):
         self.sess = sess
-        self.batch_size = opts.batch_size
-        self.image_size = opts.fine_size
-        self.input_c_dim = opts.input_nc
-        self.output_c_dim = opts.output_nc
-        self.L1_lambda = opts.L1_lambda
-        self.dataset_dir = os.path.join(getattr(opts, 'data_dir', 'data'), opts.dataset)
+        # cyclegan.py:22-40: attribute names as in the reference
+        self.batch_size, self.image_size, self.L1_lambda = opts.batch_size, opts.fine_size, opts.L1_lambda
+        self.input_c_dim, self.output_c_dim = opts.input_nc, opts.output_nc
         self.dataset = opts.dataset
-
+        self.dataset_dir = os.path.join(getattr(opts, 'data_dir', 'data'), opts.dataset)
         self.discriminator = discriminator
-        if opts.use_resnet:
-            self.generator = generator_resnet
-        else:
-            self.generator = generator_unet
-        if opts.use_lsgan:
-            self.criterionGAN = mae_criterion
-        else:
-            self.criterionGAN = sce_criterion
-
-        self.options = opts
-        self.options.image_size = opts.fine_size
-        self.options.output_c_dim = opts.output_nc
+        self.generator = generator_resnet if opts.use_resnet else generator_unet
+        self.criterionGAN = mae_criterion if opts.use_lsgan else sce_criterion
+        self.options = opts                     # handed on to the network functions, which read these two from it
+        opts.image_size, opts.output_c_dim = opts.fine_size, opts.output_nc
 
         self.model_dir = "%s_%s" % (self.dataset, self.image_size)
         self.world_size, self.process_group = world_size, process_group

@@ -43,20 +43,11 @@ class DCGAN(object):
         self.model = getattr(options, 'model', 'DCGAN')
         self.crop = getattr(options, 'crop', True)
 
-        self.batch_size = options.batch_size
-        self.sample_num = options.batch_size
-
-        self.input_height = options.input_height
-        self.input_width = options.input_width
-        self.output_height = options.output_height
-        self.output_width = options.output_width
-
-        self.y_dim = options.y_dim
-        self.z_dim = options.z_dim
-        self.gf_dim = options.gf_dim
-        self.df_dim = options.df_dim
-        self.gfc_dim = options.gfc_dim
-        self.dfc_dim = options.dfc_dim
+        # dcgan.py:31-54: attribute names as in the reference, read from the same options
+        self.batch_size = self.sample_num = options.batch_size
+        for name in ('input_height', 'input_width', 'output_height', 'output_width', 'y_dim', 'z_dim', 'gf_dim', 'df_dim',
+                     'gfc_dim', 'dfc_dim'):
+            setattr(self, name, getattr(options, name))
         self.print_every = getattr(options, 'print_every', 1)
 
         self.world_size = world_size

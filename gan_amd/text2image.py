@@ -34,39 +34,22 @@ class Text2Image(object):
     '''
 
     def __init__(self, sess, options, store=None, world_size=1, process_group=None):
-        self.textEncoder = options.textEncoder
         self.sess = sess
         self.model = getattr(options, 'model', 'Text2Image')
-        self.image_size = options.input_height
-        self.batch_size = options.batch_size
-        self.z_dim = options.z_dim
-        if options.caption_vector_length is not None:
-            self.caption_vector_length = options.caption_vector_length
-        else:
-            if options.textEncoder == 'skipthought':
-                self.caption_vector_length = 2400
-            elif options.textEncoder == 'DSSJE':
-                self.caption_vector_length = 1024
-            else:
-                raise ValueError('unknown text encoder')
-        if options.textEncoder == 'skipthought':
-            self.nCapsPerImage = 5
-        elif options.textEncoder == 'DSSJE':
-            self.nCapsPerImage = 10
-        else:
+        # text2image.py:36-59: the same attribute names, read from the same options
+        encoders = {'skipthought': (2400, 5), 'DSSJE': (1024, 10)}      # caption vector length, captions per image
+        if options.textEncoder not in encoders:
             raise ValueError('unknown text encoder')
-        self.t_dim = options.t_dim
-        self.gf_dim = options.gf_dim
-        self.df_dim = options.df_dim
-        self.sample_dir = getattr(options, 'sample_dir', './samples')
-        self.checkpoint_dir = getattr(options, 'checkpoint_dir', './checkpoint')
-        self.nEpochs = options.nEpochs
-        self.dataset = options.dataset
-        self.lr = options.lr
-        self.beta1 = options.beta1
-        self.resume_model = getattr(options, 'resume_model', None)
-        self.data_dir = getattr(options, 'data_dir', 'data')
-        self.save_every_batch = getattr(options, 'save_every_batch', 50)
+        self.textEncoder = options.textEncoder
+        default_length, self.nCapsPerImage = encoders[self.textEncoder]
+        self.caption_vector_length = (options.caption_vector_length if options.caption_vector_length is not None
+                                      else default_length)
+        self.image_size = options.input_height
+        for name in ('batch_size', 'z_dim', 't_dim', 'gf_dim', 'df_dim', 'nEpochs', 'dataset', 'lr', 'beta1'):
+            setattr(self, name, getattr(options, name))
+        for name, default in (('sample_dir', './samples'), ('checkpoint_dir', './checkpoint'), ('resume_model', None),
+                              ('data_dir', 'data'), ('save_every_batch', 50)):
+            setattr(self, name, getattr(options, name, default))
         self.use_graph = bool(getattr(options, 'use_graph', True))
         self.prefetch_batches = int(getattr(options, 'prefetch_batches', 4))
         self._runner = None
