@@ -56,16 +56,10 @@ class DCGAN(object):
         self.stack_d_passes = True      # D update: D(real) and D(fake) as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
 
-        # batch normalization : deals with poor initialization helps gradient flow (dcgan.py:56-68)
-        self.d_bn1 = batch_norm(name='d_bn1')
-        self.d_bn2 = batch_norm(name='d_bn2')
-        if not self.y_dim:
-            self.d_bn3 = batch_norm(name='d_bn3')
-        self.g_bn0 = batch_norm(name='g_bn0')
-        self.g_bn1 = batch_norm(name='g_bn1')
-        self.g_bn2 = batch_norm(name='g_bn2')
-        if not self.y_dim:
-            self.g_bn3 = batch_norm(name='g_bn3')
+        # the batch-norm layers by name (dcgan.py:56-68); the conditional networks are one layer shallower
+        names = ['d_bn1', 'd_bn2', 'g_bn0', 'g_bn1', 'g_bn2'] + ([] if self.y_dim else ['d_bn3', 'g_bn3'])
+        for name in names:
+            setattr(self, name, batch_norm(name=name))
 
         self.dataset = options.dataset
         self.input_fname_pattern = getattr(options, 'input_fname_pattern', '*.jpg')
@@ -178,11 +172,10 @@ class DCGAN(object):
                 scope.reuse_variables()
             bs = self.batch_size
             if not self.y_dim:
+                # spatial sizes of the five stages, halving with ceil (dcgan.py:357-361)
                 s_h, s_w = self.output_height, self.output_width
-                s_h2, s_w2 = conv_out_size_same(s_h, 2), conv_out_size_same(s_w, 2)
-                s_h4, s_w4 = conv_out_size_same(s_h2, 2), conv_out_size_same(s_w2, 2)
-                s_h8, s_w8 = conv_out_size_same(s_h4, 2), conv_out_size_same(s_w4, 2)
-                s_h16, s_w16 = conv_out_size_same(s_h8, 2), conv_out_size_same(s_w8, 2)
+                (s_h2, s_w2), (s_h4, s_w4), (s_h8, s_w8), (s_h16, s_w16) = [
+                    (conv_out_size_same(s_h, d), conv_out_size_same(s_w, d)) for d in (2, 4, 8, 16)]
                 # project `z` and reshape
                 self.t_z_, self.h0_w, self.h0_b = linear(z, self.gf_dim * 8 * s_h16 * s_w16, 'g_h0_lin', with_w=True)
                 self.h0 = self.t_z_.reshape(-1, s_h16, s_w16, self.gf_dim * 8)

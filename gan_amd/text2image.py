@@ -22,16 +22,9 @@ from .optim import AdamOptimizer
 
 
 class Text2Image(object):
-    '''
-    OPTIONS (text2image.py:16-25)
-    z_dim : Noise dimension 100
-    t_dim : Text feature dimension 256
-    image_size : Image Dimension 64
-    gf_dim : Number of conv in the first layer generator 64
-    df_dim : Number of conv in the first layer discriminator 64
-    caption_vector_length : Caption Vector Length 2400 (skipthought) / 1024 (DSSJE)
-    batch_size : Batch Size 64
-    '''
+    '''Text-to-image GAN-CLS (text2image.py).  Options read (text2image.py:16-25 lists them): z_dim (noise, 100),
+    t_dim (reduced text feature, 256), input_height (image size, 64), gf_dim / df_dim (first-layer filters, 64),
+    caption_vector_length (2400 skip-thought / 1024 DS-SJE unless given), batch_size (64), textEncoder.'''
 
     def __init__(self, sess, options, store=None, world_size=1, process_group=None):
         self.sess = sess
@@ -58,15 +51,8 @@ class Text2Image(object):
         self.stack_d_passes = True      # D update: the three D applications as one stacked batch
         self.store = store if store is not None else V.VariableStore(seed=getattr(options, 'seed', 0))
 
-        self.g_bn0 = ops.batch_norm(name='g_bn0')
-        self.g_bn1 = ops.batch_norm(name='g_bn1')
-        self.g_bn2 = ops.batch_norm(name='g_bn2')
-        self.g_bn3 = ops.batch_norm(name='g_bn3')
-
-        self.d_bn1 = ops.batch_norm(name='d_bn1')
-        self.d_bn2 = ops.batch_norm(name='d_bn2')
-        self.d_bn3 = ops.batch_norm(name='d_bn3')
-        self.d_bn4 = ops.batch_norm(name='d_bn4')
+        for name in ('g_bn0', 'g_bn1', 'g_bn2', 'g_bn3', 'd_bn1', 'd_bn2', 'd_bn3', 'd_bn4'):     # text2image.py:61-69
+            setattr(self, name, ops.batch_norm(name=name))
 
         self.build_model()
 
