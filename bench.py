@@ -3,8 +3,10 @@
 
 One step = one iteration of the reference's loop body (models/dcgan.py:262-275): one D update and
 two G updates on a batch of 64 synthetic 64x64x3 images per GPU, fp32, inputs resident in HBM.
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run,
-one rank per GPU, gradients all-reduced with RCCL.  Rank 0 prints ONE JSON line.
+`python bench.py --gpus N --steps K --warmup W`; N > 1 runs one rank per GPU with the gradients
+all-reduced over RCCL: either under torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the
+environment) or, called plainly, by starting that job itself as a child process.  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
@@ -163,6 +165,36 @@ def cpu_baseline(iters):
                       "CPU restatement, not TensorFlow" % iters}
 
 
+def launch_ranks(n, backend):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as a CHILD job
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), hand its one JSON line on and
+    return its exit code.  Runs before anything in this process has touched the GPU, and replaces no
+    process image: the parent only waits."""
+    import socket
+    import subprocess
+    seen = torch.cuda.device_count()        # counts devices without initialising the runtime
+    if backend == "nccl" and seen < n:
+        sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this machine (RCCL needs one per rank; "
+                         "--backend gloo rehearses several ranks on one GPU)\n" % (n, seen))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in child.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if child.returncode == 0 and not lines:
+        sys.stderr.write("bench.py --gpus %d: the ranks exited cleanly but printed no JSON line\n" % n)
+        return 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return child.returncode
+
+
 def main():
     global BATCH
     ap = argparse.ArgumentParser()
@@ -183,8 +215,13 @@ def main():
                     help="images per GPU per step; 64 is the benchmark's configuration, other values are for exploration "
                          "and are named in config.workload")
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the multi-rank launch: the ranks join the group, count each other with an "
+                         "all-reduce and rank 0 prints {\"launch_check\": true, \"n_ranks_seen\": N}; no GPU work")
     args = ap.parse_args()
     nominal_batch, BATCH = BATCH, args.batch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, args.backend))
 
     # Libraries underneath (RCCL's version banner) write to stdout; the contract is ONE JSON line
     # there, so everything before the final print goes to stderr instead.
@@ -197,6 +234,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
+    if args.launch_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"launch_check": True, "n_gpus": args.gpus, "n_ranks_seen": seen}) + "\n").encode())
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
     if args.backend == "gloo":
@@ -297,7 +347,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "DCGAN-64 G+D train images/sec", "value": round(BATCH * world * args.steps / elapsed, 2),
-            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "images/s", "n_gpus": world, "n_ranks_seen": (dist.get_world_size() if dist is not None else 1),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DCGAN 64x64x3 CelebA-shaped synthetic images, batch %d per GPU%s, fp32, "
