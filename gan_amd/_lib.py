@@ -71,6 +71,7 @@ SIGNATURES = {
     "gan_conv_plan_get": (I, [I, GeomP, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
     "gan_conv_plan_clear": (None, []),
     "gan_linear_as_conv_geom": (I, [I, I, I, GeomP]),
+    "gan_knob_set": (I, [ctypes.c_char_p, I]),
     "gan_set_exact_f32": (None, [I]),
     "gan_get_exact_f32": (I, []),
 }
@@ -83,6 +84,12 @@ for _name, (_res, _args) in SIGNATURES.items():
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU,
              'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
+
+
+def knob_set(name, value):
+    """Set a test / tuning knob of the library (include/gan_hip.h, gan_knob_set)."""
+    if lib.gan_knob_set(name.encode(), int(value)) != 0:
+        raise ValueError(lib.gan_last_error().decode())
 
 
 class GanHipError(RuntimeError):

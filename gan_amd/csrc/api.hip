@@ -1,5 +1,6 @@
 // extern "C" entry points of the contraction family (conv2d, conv2d_transpose, linear)
 // and the library-wide error channel.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -37,6 +38,32 @@ int fail(const char* fmt, ...) {
     return 1;
 }
 
+static int env_int(const char* name, int unset) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : unset;
+}
+static int env_flag(const char* name) {
+    const char* e = getenv(name);
+    return (e && *e && *e != '0') ? 1 : 0;
+}
+
+Knobs& knobs() {
+    static Knobs k = [] {
+        Knobs r;
+        r.force_cfg = env_int("GAN_HIP_FORCE_CFG", -1);
+        r.force_splits = env_int("GAN_HIP_FORCE_SPLITS", 0);
+        if (r.force_splits < 0) r.force_splits = 0;
+        r.no_thin = getenv("GAN_HIP_NO_THIN") != nullptr;
+        r.slow_gather = getenv("GAN_HIP_SLOW_GATHER") != nullptr;
+        r.scalar_epilogue = getenv("GAN_HIP_SCALAR_EPILOGUE") != nullptr;
+        r.three_launch_bn = getenv("GAN_HIP_THREE_LAUNCH_BN") != nullptr;
+        r.separate_colsum = getenv("GAN_HIP_SEPARATE_COLSUM") != nullptr;
+        r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
+        return r;
+    }();
+    return k;
+}
+
 static gan_conv_geom linear_geom(int rows, int in_dim, int out_dim) {
     gan_conv_geom g;
     g.n = rows;
@@ -61,7 +88,7 @@ static int wgrad_with_bias(const gan_conv_geom& g, const float* a, const float* 
                            const char* what) {
     if (db == nullptr)
         return run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, ws_bytes, st, what);
-    if (getenv("GAN_HIP_SEPARATE_COLSUM")) {        // test knob: the column sum as two launches of its own, afterwards
+    if (knobs().separate_colsum) {        // test knob: the column sum as two launches of its own, afterwards
         if (int rc = run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, ws_bytes, st, what)) return rc;
         ColsumFinal sep;
         if (int rc = colsum_partial(dy_rows, rows, c, ws, ws_bytes, st, what, &sep)) return rc;
@@ -76,7 +103,9 @@ static int wgrad_with_bias(const gan_conv_geom& g, const float* a, const float* 
     job.out = db;
     job.accumulate = accumulate;
     int done = 0;
-    if (int rc = run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, ws_bytes, st, what, &job, &done))
+    // the slabs may use only the `off` bytes in front of the partial sums: a plan that needs more (it cannot,
+    // the size query covers the aligned and the unaligned plan) fails instead of overwriting them
+    if (int rc = run_igemm_geom(MODE_WGRAD, g, a, b, dw, nullptr, accumulate, g.cs, ws, off, st, what, &job, &done))
         return rc;
     return done ? 0 : colsum_final(job, st, what);
 }
@@ -224,7 +253,7 @@ __global__ __launch_bounds__(256) void linear_thin_wgrad_kernel(const float* __r
 }
 
 static bool thin_linear_ok(int in_dim, int out_dim) {
-    return out_dim <= kThinLinMaxOut && in_dim >= 256 && getenv("GAN_HIP_NO_THIN") == nullptr;
+    return out_dim <= kThinLinMaxOut && in_dim >= 256 && !knobs().no_thin;
 }
 
 #define GAN_THIN_LIN_DISPATCH(KERNEL, GRID, BLOCK, ...)                                            \
@@ -313,6 +342,20 @@ extern "C" int gan_conv_plan_get(int mode, const gan_conv_geom* g, int* cfg, int
 }
 
 extern "C" void gan_conv_plan_clear(void) { plan_clear(); }
+
+extern "C" int gan_knob_set(const char* name, int value) {
+    GAN_CHECK_ARG(name != nullptr, "gan_knob_set: NULL name");
+    Knobs& k = knobs();
+    if (!strcmp(name, "force_cfg")) k.force_cfg = value < 0 ? -1 : value;
+    else if (!strcmp(name, "force_splits")) k.force_splits = value > 0 ? value : 0;
+    else if (!strcmp(name, "no_thin")) k.no_thin = value != 0;
+    else if (!strcmp(name, "slow_gather")) k.slow_gather = value != 0;
+    else if (!strcmp(name, "scalar_epilogue")) k.scalar_epilogue = value != 0;
+    else if (!strcmp(name, "three_launch_bn")) k.three_launch_bn = value != 0;
+    else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
+    else return fail("gan_knob_set: unknown knob '%s'", name);
+    return 0;
+}
 
 extern "C" void gan_set_exact_f32(int on) { set_exact_f32(on); }
 extern "C" int gan_get_exact_f32(void) { return get_exact_f32(); }

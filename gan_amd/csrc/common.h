@@ -24,6 +24,21 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+// Test and tuning knobs.  Their initial values come from the environment (GAN_HIP_*), read ONCE at first
+// use, so that a launch costs no getenv and a plan cannot change between a workspace query and the run it
+// sizes; gan_knob_set changes them afterwards (tests, tuners).
+struct Knobs {
+    int force_cfg;      // GAN_HIP_FORCE_CFG: tile configuration of every contraction, -1 = unset
+    int force_splits;   // GAN_HIP_FORCE_SPLITS: split-K factor of every contraction, 0 = unset
+    int no_thin;        // GAN_HIP_NO_THIN: thin outputs stay on the MFMA path
+    int slow_gather;    // GAN_HIP_SLOW_GATHER: general gather arithmetic in the split kernel
+    int scalar_epilogue;  // GAN_HIP_SCALAR_EPILOGUE: dword stores instead of the 16-byte epilogue
+    int three_launch_bn;  // GAN_HIP_THREE_LAUNCH_BN: small batch norms on the general path
+    int separate_colsum;  // GAN_HIP_SEPARATE_COLSUM: bias gradients as launches of their own
+    int exact_f32;      // GAN_HIP_EXACT_F32: default of gan_set_exact_f32
+};
+Knobs& knobs();
+
 inline hipStream_t as_stream(gan_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int kWave = 64;

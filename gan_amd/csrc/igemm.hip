@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -703,15 +704,18 @@ constexpr int kFirstSplitCfg = 4, kNumCfg = 7;
 // Process-wide switch: 1 keeps every contraction on the fp32 MFMA (bitwise an fmaf chain); 0 lets
 // layers whose channel counts are multiples of 4 run on the bf16 matrix pipe with fp32 operands
 // split into three bf16 parts (igemm_split.h).  GAN_HIP_EXACT_F32 in the environment sets the default.
-static int g_exact_f32 = -1;
+// It selects plans and therefore workspace sizes: set it before the first query, not while another
+// thread is inside a contraction call.
+static std::atomic<int> g_exact_f32{-1};
 static bool exact_f32() {
-    if (g_exact_f32 < 0) {
-        const char* e = getenv("GAN_HIP_EXACT_F32");
-        g_exact_f32 = (e && *e && *e != '0') ? 1 : 0;
+    int v = g_exact_f32.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = knobs().exact_f32 ? 1 : 0;
+        g_exact_f32.store(v, std::memory_order_relaxed);
     }
-    return g_exact_f32 == 1;
+    return v == 1;
 }
-void set_exact_f32(int on) { g_exact_f32 = on ? 1 : 0; }
+void set_exact_f32(int on) { g_exact_f32.store(on ? 1 : 0, std::memory_order_relaxed); }
 int get_exact_f32() { return exact_f32() ? 1 : 0; }
 
 static int geom_check(const gan_conv_geom& g) {
@@ -783,7 +787,16 @@ static std::mutex g_plan_mu;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
-static Plan make_plan(int mode, const IgemmArgs& a) {
+// The split kernel's loaders move 16 / 8 bytes at a time: both gathered channel counts must be multiples
+// of 4 and both operands below 4 GB (a_bytes / b_bytes are 0 beyond that).
+static bool split_eligible(int mode, const IgemmArgs& a) {
+    const gan_conv_geom& g = a.g;
+    const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0) : (g.cb % 4 == 0 && g.cs % 4 == 0);
+    return ch && a.a_bytes != 0 && a.b_bytes != 0;
+}
+
+// `a_al` / `b_al`: the operand pointers are 16-byte aligned (vector loads, split kernel eligible).
+static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     const gan_conv_geom& g = a.g;
     Plan pl;
     int M, N, K;
@@ -802,13 +815,13 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
         pl.va = (g.cb % 4 == 0) ? 4 : 1;
         pl.vb = (g.cs % 4 == 0) ? 4 : 1;
     }
-    if (!aligned16(a.a)) pl.va = 1;
-    if (!aligned16(a.b)) pl.vb = 1;
+    if (!a_al) pl.va = 1;
+    if (!b_al) pl.vb = 1;
     if (N <= 32) pl.cfg = 3;
     else if (N <= 64) pl.cfg = (M >= 8192) ? 1 : 2;
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
     // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4
-    const bool split_ok = pl.va == 4 && pl.vb == 4 && a.a_bytes != 0 && a.b_bytes != 0 && !exact_f32();
+    const bool split_ok = a_al && b_al && split_eligible(mode, a) && !exact_f32();
     if (split_ok && pl.cfg < 3) {
         // the split kernel converts every staged value, so it wants the largest tile that still leaves
         // enough blocks: 128x128 from 1024 rows on (the tuned DCGAN / CycleGAN plans agree)
@@ -824,8 +837,9 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
             pinned_splits = it->second.second;
         }
     }
-    if (const char* e = getenv("GAN_HIP_FORCE_CFG")) pl.cfg = atoi(e) % kNumCfg;
-    if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;   // pinned or forced, but not eligible
+    if (knobs().force_cfg >= 0) pl.cfg = knobs().force_cfg % kNumCfg;
+    // a pinned or forced split configuration on operands that cannot take it (unaligned views, exact mode)
+    if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;
     const int bm = kCfg[pl.cfg].bm, bn = kCfg[pl.cfg].bn;
     pl.mt = (M + bm - 1) / bm;
     pl.nt = (N + bn - 1) / bn;
@@ -846,7 +860,7 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
         if (splits < 1) splits = 1;
     }
     if (pinned_splits > 0) splits = pinned_splits;
-    if (const char* e = getenv("GAN_HIP_FORCE_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : 1;
+    if (knobs().force_splits > 0) splits = knobs().force_splits;
     pl.kt_per_split = nkt > 0 ? (nkt + splits - 1) / splits : 1;
     pl.splits = nkt > 0 ? (nkt + pl.kt_per_split - 1) / pl.kt_per_split : 1;
     if (pl.splits < 1) pl.splits = 1;
@@ -858,7 +872,7 @@ static Plan make_plan(int mode, const IgemmArgs& a) {
 static bool thin_tprop_ok(const IgemmArgs& a) {
     const gan_conv_geom& g = a.g;
     if (g.cb > 4 || g.cs % kThinCC != 0 || a.accumulate) return false;
-    if (!aligned16(a.a) || getenv("GAN_HIP_FORCE_CFG") || getenv("GAN_HIP_NO_THIN")) return false;
+    if (!aligned16(a.a) || knobs().force_cfg >= 0 || knobs().no_thin) return false;
     for (int i = 0; i < a.ncls; ++i)
         if (a.cls[i].khc > kThinMaxTaps || a.cls[i].kwc > kThinMaxTaps) return false;
     return true;
@@ -916,7 +930,7 @@ static void launch_split(const IgemmArgs& a, dim3 grid, hipStream_t s) {
     const gan_conv_geom& g = a.g;
     const bool fast = (MODE == MODE_FPROP) ? (g.cb % 16 == 0)
                     : (MODE == MODE_TPROP) ? (g.cs % 16 == 0) : (g.ws % 4 == 0);
-    if (fast && !getenv("GAN_HIP_SLOW_GATHER"))
+    if (fast && !knobs().slow_gather)
         hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, true>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false>), grid, dim3(256), 0, s, a);
@@ -949,7 +963,7 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
     if (mode == MODE_TPROP && thin_tprop_ok(a)) return run_thin_tprop(a, s, what);
-    Plan pl = make_plan(mode, a);
+    Plan pl = make_plan(mode, a, aligned16(a.a), aligned16(a.b));
     const size_t need = plan_ws_bytes(pl);
     GAN_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= need), "%s: workspace of %zu bytes needed, %zu given",
                   what, need, ws_bytes);
@@ -967,7 +981,7 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     {
         const int n_out = (mode == MODE_TPROP) ? a.g.cb : a.N;
         a.vec_epilogue = ((n_out & 3) == 0 && (pl.out_elems & 3) == 0 && aligned16(a.out) && aligned16(final_out) &&
-                          (bias == nullptr || aligned16(bias)) && !getenv("GAN_HIP_SCALAR_EPILOGUE")) ? 1 : 0;
+                          (bias == nullptr || aligned16(bias)) && !knobs().scalar_epilogue) ? 1 : 0;
     }
     dim3 grid(pl.mt, pl.nt, pl.splits * a.ncls);
     switch (mode) {
@@ -999,9 +1013,12 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
 size_t igemm_ws_bytes(int mode, IgemmArgs a) {
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
-    // alignment of the (unknown) pointers does not change the split plan
-    a.a = a.b = nullptr;
-    return plan_ws_bytes(make_plan(mode, a));
+    // The pointers are not known yet, and their alignment selects the kernel family (16-byte aligned
+    // operands take the split kernel, others the fp32 kernel with a different block target and hence
+    // split-K factor): report the larger of the two plans' needs.
+    const size_t al = plan_ws_bytes(make_plan(mode, a, true, true));
+    const size_t un = plan_ws_bytes(make_plan(mode, a, false, false));
+    return al > un ? al : un;
 }
 
 IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out,
@@ -1037,6 +1054,12 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
 }
 
 int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits) {
+    if (cfg >= kFirstSplitCfg) {
+        const IgemmArgs a = make_args(mode, g, nullptr, nullptr, nullptr, nullptr, 0);
+        GAN_CHECK_ARG(split_eligible(mode, a),
+                      "gan_conv_plan_set: tile configuration %d (bf16 matrix pipe) needs channel counts that are "
+                      "multiples of 4 and operands below 4 GB; this geometry runs configurations 0..3", cfg);
+    }
     std::lock_guard<std::mutex> lock(g_plan_mu);
     if (cfg < 0) plan_table().erase(plan_key(mode, g));
     else plan_table()[plan_key(mode, g)] = std::make_pair(cfg % kNumCfg, splits);
@@ -1054,7 +1077,7 @@ void plan_get(int mode, const gan_conv_geom& g, int* cfg, int* splits, int* thin
     IgemmArgs a = make_args(mode, g, dummy, dummy, nullptr, nullptr, 0);
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
-    const Plan pl = make_plan(mode, a);
+    const Plan pl = make_plan(mode, a, true, true);
     *cfg = pl.cfg;
     *splits = pl.splits;
     *thin = (mode == MODE_TPROP && thin_tprop_ok(a)) ? 1 : 0;

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
 static bool fused_bn_ok(int rows, int c, const void* p0, const void* p1, const void* p2, const void* p3) {
     auto a16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return rows <= kFusedMaxRows && (c & 3) == 0 && a16(p0) && a16(p1) && a16(p2) && a16(p3) &&
-           !getenv("GAN_HIP_THREE_LAUNCH_BN");
+           !knobs().three_launch_bn;
 }
 
 #define GAN_FUSED_BN_DISPATCH(KERNEL, rows, GRID, st, ...)                                            \

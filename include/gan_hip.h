@@ -203,14 +203,21 @@ int gan_linear_as_conv_geom(int rows, int in_dim, int out_dim, gan_conv_geom* g)
 void gan_set_exact_f32(int on);
 int gan_get_exact_f32(void);
 
-/* Environment variables read at call time, for tests and tuning only (none is needed in production):
- *   GAN_HIP_FORCE_CFG=<0..6>, GAN_HIP_FORCE_SPLITS=<n>  override the plan of every contraction;
- *   GAN_HIP_NO_THIN=1         keeps thin outputs (<= 4 channels / <= 4 linear outputs) on the MFMA path;
- *   GAN_HIP_SLOW_GATHER=1     general gather arithmetic in the split kernel (results are bit-identical);
- *   GAN_HIP_SCALAR_EPILOGUE=1 dword stores instead of the 16-byte epilogue;
- *   GAN_HIP_THREE_LAUNCH_BN=1 keeps small batch norms (<= 1024 rows per group) on the general three-launch path;
- *   GAN_HIP_SEPARATE_COLSUM=1 bias gradients as two launches after the weight gradient instead of one before it
- *                             and a last stage carried by the slab reduction's launch (results are bit-identical). */
+/* ---- test and tuning knobs (no counterpart in the reference; none is needed in production) ------
+ * Each knob takes its initial value from an environment variable, read ONCE at the first call into
+ * the library (no getenv on the launch path; a plan cannot change between a workspace query and the
+ * call it sizes), and can be changed afterwards with gan_knob_set(name, value):
+ *   "force_cfg"       GAN_HIP_FORCE_CFG=<0..6>   tile configuration of every contraction (-1: unset)
+ *   "force_splits"    GAN_HIP_FORCE_SPLITS=<n>   split-K factor of every contraction (0: unset)
+ *   "no_thin"         GAN_HIP_NO_THIN=1          thin outputs (<= 4 channels / linear outputs) stay on the MFMA path
+ *   "slow_gather"     GAN_HIP_SLOW_GATHER=1      general gather arithmetic in the split kernel (bit-identical)
+ *   "scalar_epilogue" GAN_HIP_SCALAR_EPILOGUE=1  dword stores instead of the 16-byte epilogue
+ *   "three_launch_bn" GAN_HIP_THREE_LAUNCH_BN=1  small batch norms (<= 1024 rows per group) on the general path
+ *   "separate_colsum" GAN_HIP_SEPARATE_COLSUM=1  bias gradients as two launches after the weight gradient
+ *                                                (bit-identical to the default, fused placement)
+ * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe
+ * against concurrent calls into the library. */
+int gan_knob_set(const char* name, int value);
 
 /* ---- utilities ------------------------------------------------------------------------- */
 int gan_fill(float* x, long n, float value, gan_stream_t stream);

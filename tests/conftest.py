@@ -22,3 +22,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _library_knobs_back_to_default(request):
+    """Tests flip the library's tuning knobs (gan_knob_set); none may leak into the next test."""
+    yield
+    if "gpu" not in request.keywords:
+        return
+    from gan_amd._lib import knob_set
+    for name, unset in (("force_cfg", -1), ("force_splits", 0), ("no_thin", 0), ("slow_gather", 0),
+                        ("scalar_epilogue", 0), ("three_launch_bn", 0), ("separate_colsum", 0)):
+        knob_set(name, unset)

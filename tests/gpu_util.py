@@ -62,22 +62,32 @@ class forced(object):
     """Force a tile configuration / split-K factor of the contraction kernels for one block."""
 
     def __init__(self, cfg=None, splits=None):
-        self.env = {"GAN_HIP_FORCE_CFG": cfg, "GAN_HIP_FORCE_SPLITS": splits}
+        self.cfg, self.splits = cfg, splits
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.env}
-        for k, v in self.env.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
+        from gan_amd._lib import knob_set
+        knob_set("force_cfg", -1 if self.cfg is None else int(self.cfg))
+        knob_set("force_splits", 0 if self.splits is None else int(self.splits))
 
     def __exit__(self, *exc):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        from gan_amd._lib import knob_set
+        knob_set("force_cfg", -1)
+        knob_set("force_splits", 0)
+
+
+class knob(object):
+    """Turn one boolean library knob on for one block."""
+
+    def __init__(self, name, on=True):
+        self.name, self.on = name, on
+
+    def __enter__(self):
+        from gan_amd._lib import knob_set
+        knob_set(self.name, 1 if self.on else 0)
+
+    def __exit__(self, *exc):
+        from gan_amd._lib import knob_set
+        knob_set(self.name, 0)
 
 
 def geom_for(n, h, w, cb, cs, k, s, padding):

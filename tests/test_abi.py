@@ -78,7 +78,10 @@ def test_plan_pinning_is_host_side_bookkeeping():
     L.lib.gan_set_exact_f32(0)
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     godd = L.conv_geom(8, 16, 16, 6, 8, 8, 10, 5, 5, 2, 2, 1, 1)
-    L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 6, 1))
+    # a geometry that cannot take the split kernels (odd channel counts): the pin is refused, so that
+    # what is pinned is exactly what runs
+    assert L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 6, 1) != 0 and b"multiples of 4" in L.lib.gan_last_error()
+    L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 2, 1))
     L.check(L.lib.gan_conv_plan_get(0, ctypes.byref(godd), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
     assert c.value == 2
     # thin outputs of the transposed contraction have no plan
@@ -89,3 +92,9 @@ def test_plan_pinning_is_host_side_bookkeeping():
     L.check(L.lib.gan_linear_as_conv_geom(64, 100, 8192, ctypes.byref(lg)))
     assert (lg.n, lg.cb, lg.cs, lg.kh, lg.hb) == (64, 100, 8192, 1, 1)
     L.lib.gan_conv_plan_clear()
+    # knobs: initial values from the environment once, changed through the setter only
+    assert L.lib.gan_knob_set(b"no_such_knob", 1) != 0 and b"unknown knob" in L.lib.gan_last_error()
+    L.knob_set("force_cfg", 2)
+    assert get(0)[0] == 2
+    L.knob_set("force_cfg", -1)
+    assert get(0) == heur

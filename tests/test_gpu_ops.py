@@ -343,7 +343,7 @@ def test_one_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows
     outs = []
     for general in (False, True):
         if general:
-            monkeypatch.setenv("GAN_HIP_THREE_LAUNCH_BN", "1")
+            L.knob_set("three_launch_bn", 1)
         mm, mv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
         y, dx = torch.empty_like(x), torch.empty_like(x)
         sm, sr = torch.empty(groups * c, device='cuda'), torch.empty(groups * c, device='cuda')
@@ -540,7 +540,7 @@ def test_split_kernel_gather_variants_agree_bitwise(L, case, monkeypatch):
     outs = []
     for slow in (False, True):
         if slow:
-            monkeypatch.setenv("GAN_HIP_SLOW_GATHER", "1")
+            L.knob_set("slow_gather", 1)
         y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(wt)
         wp, wn = _ws(L, g)
         st = L.stream()
@@ -572,7 +572,7 @@ def test_bias_gradient_carried_by_the_slab_reduction_is_bit_identical(L, case, a
     outs = []
     for separate in (False, True):
         if separate:
-            monkeypatch.setenv("GAN_HIP_SEPARATE_COLSUM", "1")
+            L.knob_set("separate_colsum", 1)
         torch.manual_seed(3)
         dw, db = torch.randn(k, k, cb, cs, device='cuda'), torch.randn(cs, device='cuda')       # accumulate onto these
         dwt, dbt = torch.randn(k, k, cb, cs, device='cuda'), torch.randn(cb, device='cuda')
@@ -648,3 +648,34 @@ def test_fork_sums_the_gradients_of_its_consumers(L):
     with torch.no_grad():
         assert ops.fork(x)[1] is x
     assert ops.fork(x.detach())[0] is not None and ops.fork(x.detach())[0].requires_grad is False
+
+
+def test_weight_and_bias_gradient_of_unaligned_views(L):
+    """Operand pointers that are not 16-byte aligned (views one float into a buffer) switch the weight-gradient
+    contraction from the split kernel to the fp32 kernel, whose plan takes more split-K slabs: the workspace
+    query covers both plans, and the bias-gradient partial sums that share the workspace stay intact."""
+    from gpu_util import geom_for, assert_close, host
+    g = geom_for(2, 16, 16, 128, 256, 5, 2, 'SAME')          # filter gradient of 3200 x 256: few tiles, many slabs
+    gp = ctypes.byref(g)
+    torch.manual_seed(11)
+    xb = torch.randn(2 * 16 * 16 * 128 + 1, device='cuda')
+    dyb = torch.randn(2 * 8 * 8 * 256 + 1, device='cuda')
+    outs = []
+    for shift in (0, 1):
+        x = xb[shift:shift + 2 * 16 * 16 * 128]
+        dy = dyb[shift:shift + 2 * 8 * 8 * 256]
+        if shift == 0:
+            x0, dy0 = x.clone(), dy.clone()
+        else:
+            x.copy_(x0)
+            dy.copy_(dy0)
+            assert x.data_ptr() % 16 == 4 and dy.data_ptr() % 16 == 4
+        dw, db = torch.empty(5, 5, 128, 256, device='cuda'), torch.empty(256, device='cuda')
+        wp, wn = _ws(L, g)
+        L.check(L.lib.gan_conv2d_wgrad(gp, x.data_ptr(), dy.data_ptr(), L.ptr(dw), L.ptr(db), 0, wp, wn, L.stream()))
+        torch.cuda.synchronize()
+        outs.append((host(dw), host(db)))
+    ref_db = host(dy0.view(-1, 256).double().sum(0))
+    for dw, db in outs:
+        assert_close(db, ref_db, "bias gradient", tol=1e-5)
+    assert_close(outs[1][0], outs[0][0], "weight gradient of the unaligned views", tol=1e-5)

@@ -82,12 +82,12 @@ def main():
         for p in PASSES:
             if args.only and args.only != "%s:%s" % (lname, p):
                 continue
-            os.environ.pop("GAN_HIP_FORCE_CFG", None)
-            os.environ.pop("GAN_HIP_FORCE_SPLITS", None)
+            L.knob_set("force_cfg", -1)
+            L.knob_set("force_splits", 0)
             if args.cfg is not None:
-                os.environ["GAN_HIP_FORCE_CFG"] = args.cfg
+                L.knob_set("force_cfg", int(args.cfg))
             if args.splits is not None:
-                os.environ["GAN_HIP_FORCE_SPLITS"] = args.splits
+                L.knob_set("force_splits", int(args.splits))
             us = time_pass(g, p, bufs, wp, wn, args.reps)
             print("%-5s %-6s heuristic        %8.1f us  %6.1f TFLOP/s" % (lname, p, us, flops / us / 1e6), flush=True)
             if not args.sweep:
@@ -95,8 +95,8 @@ def main():
             best = None
             for cfg in range(4):
                 for splits in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-                    os.environ["GAN_HIP_FORCE_CFG"] = str(cfg)
-                    os.environ["GAN_HIP_FORCE_SPLITS"] = str(splits)
+                    L.knob_set("force_cfg", int(str(cfg)))
+                    L.knob_set("force_splits", int(str(splits)))
                     try:
                         us = time_pass(g, p, bufs, wp, wn, max(3, args.reps // 4))
                     except L.GanHipError:

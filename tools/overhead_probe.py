@@ -12,7 +12,7 @@ def timeit(fn, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 for cfg, splits in [(0, 8), (0, 16), (4, 4), (4, 8), (4, 16), (5, 4), (5, 8), (6, 2), (6, 4)]:
-    os.environ["GAN_HIP_FORCE_CFG"] = str(cfg); os.environ["GAN_HIP_FORCE_SPLITS"] = str(splits)
+    L.knob_set("force_cfg", int(str(cfg))); L.knob_set("force_splits", int(str(splits)))
     xs, ys = [], []
     for cb in (32, 64, 128, 256, 512):
         g = ops._conv_geom(64, 16, 16, cb, 256, 5, 5, 2, 2, 'SAME')

@@ -30,7 +30,7 @@ def main():
     ws = torch.empty(1 << 30, dtype=torch.uint8, device='cuda')
     wp, wn = ws.data_ptr(), ws.numel()
     if args.splits:
-        os.environ["GAN_HIP_FORCE_SPLITS"] = args.splits
+        L.knob_set("force_splits", int(args.splits))
     for lname, (n, h, w_, cb, cs, k, s) in LAYERS[1:]:
         n = args.batch
         g = ops._conv_geom(n, h, w_, cb, cs, k, k, s, s, 'SAME')
@@ -41,7 +41,7 @@ def main():
         for p in PASSES:
             ref = None
             for cfg in [int(c) for c in args.cfgs.split(",")]:
-                os.environ["GAN_HIP_FORCE_CFG"] = str(cfg)
+                L.knob_set("force_cfg", int(str(cfg)))
                 bufs = (big.clone(), small.clone(), w, torch.zeros_like(w), torch.empty(cs, device='cuda'))
                 L.check(run_pass(g, p, bufs, wp, wn))
                 torch.cuda.synchronize()
@@ -52,7 +52,7 @@ def main():
                 us = time_pass(g, p, bufs, wp, wn, args.reps)
                 print("%-5s %-6s cfg %d  %8.1f us  %6.1f TFLOP/s  max|diff|/max|ref| %.2e"
                       % (lname, p, cfg, us, flops / us / 1e6, err), flush=True)
-    os.environ.pop("GAN_HIP_FORCE_CFG", None)
+    L.knob_set("force_cfg", -1)
 
 
 if __name__ == "__main__":

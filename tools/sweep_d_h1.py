@@ -13,7 +13,7 @@ for p in ['fwd','dgrad','wgrad']:
   for cfg in range(3):
     row=[]
     for sp in (1,2,3,4,6,8,12,16):
-        os.environ['GAN_HIP_FORCE_CFG']=str(cfg); os.environ['GAN_HIP_FORCE_SPLITS']=str(sp)
+        L.knob_set("force_cfg", int(str(cfg))); L.knob_set("force_splits", int(str(sp)))
         us=kb.time_pass(g,p,(big,small,w,dw,db),ws.data_ptr(),1<<30,10)
         row.append('%d:%.0f'%(sp,us))
     print(p,'cfg',cfg,' '.join(row),flush=True)
