@@ -41,6 +41,7 @@ SIGNATURES = {
     "gan_abi_version": (I, []),
     "gan_conv_workspace_bytes": (Z, [GeomP]),
     "gan_conv2d_fwd": (I, [GeomP, P, P, P, P, P, Z, P]),
+    "gan_conv2d_fwd_static_ws": (I, [GeomP, P, P, P, P, P]),
     "gan_conv2d_dgrad": (I, [GeomP, P, P, P, P, Z, P]),
     "gan_conv2d_wgrad": (I, [GeomP, P, P, P, P, I, P, Z, P]),
     "gan_deconv2d_fwd": (I, [GeomP, P, P, P, P, P, Z, P]),

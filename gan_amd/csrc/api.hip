@@ -2,6 +2,7 @@
 // and the library-wide error channel.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 
@@ -132,6 +133,53 @@ extern "C" int gan_conv2d_fwd(const gan_conv_geom* g, const float* x, const floa
     if (int rc = conv_geom_check(g)) return rc;
     GAN_CHECK_ARG(x && w && y, "gan_conv2d_fwd: NULL tensor");
     return run_igemm_geom(MODE_FPROP, *g, x, w, y, bias, 0, g->cs, ws, ws_bytes, as_stream(stream), "gan_conv2d_fwd");
+}
+
+// ---------------------------------------------------------------------------- entry point that allocates nothing
+// The split-K slabs of gan_conv2d_fwd normally live in the caller's workspace.  This variant keeps them in a
+// device array that is part of the library's code object, so a caller that cannot allocate (HIP graph capture,
+// a serving loop, a harness that forbids hipMalloc) needs no workspace at all.  Every GPU the library runs on
+// holds its own copy of the array at its own address until the process ends; the array's name is only a
+// host-side handle, so the address is asked for once per device and used from then on.
+namespace gan {
+constexpr size_t kScratchBytes = 64u << 20;
+constexpr int kScratchMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+static void* g_scratch_ptr[kScratchMaxDevices];
+static std::mutex g_scratch_mu;
+
+// Device address of `scratch` on the current device (looked up at the first call on that device).
+static int scratch_address(void** out, const char* what) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    GAN_CHECK_ARG(e == hipSuccess, "%s: hipGetDevice failed: %s", what, hipGetErrorString(e));
+    GAN_CHECK_ARG(dev >= 0 && dev < kScratchMaxDevices, "%s: device index %d outside 0..%d", what, dev, kScratchMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        GAN_CHECK_ARG(e == hipSuccess && p != nullptr, "%s: hipGetSymbolAddress(scratch) failed on device %d: %s", what, dev,
+                      hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace gan
+
+extern "C" int gan_conv2d_fwd_static_ws(const gan_conv_geom* g, const float* x, const float* w, const float* bias,
+                                        float* y, gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(x && w && y, "gan_conv2d_fwd_static_ws: NULL tensor");
+    const size_t need = igemm_ws_bytes_geom(MODE_FPROP, *g);
+    GAN_CHECK_ARG(need <= kScratchBytes,
+                  "gan_conv2d_fwd_static_ws: this geometry needs %zu bytes of split-K slabs, the built-in scratch array "
+                  "holds %zu; use gan_conv2d_fwd with a workspace", need, (size_t)kScratchBytes);
+    void* ws = nullptr;
+    if (int rc = scratch_address(&ws, "gan_conv2d_fwd_static_ws")) return rc;
+    // every slab element a reduction reads is written by the contraction launch before it: nothing has to start at zero
+    return run_igemm_geom(MODE_FPROP, *g, x, w, y, bias, 0, g->cs, ws, kScratchBytes, as_stream(stream),
+                          "gan_conv2d_fwd_static_ws");
 }
 
 extern "C" int gan_conv2d_dgrad(const gan_conv_geom* g, const float* dy, const float* w, float* dx, void* ws,

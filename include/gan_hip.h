@@ -61,6 +61,17 @@ size_t gan_conv_workspace_bytes(const gan_conv_geom* g);
 /* y[small] = conv(x[big], w) + bias (bias may be NULL) */
 int gan_conv2d_fwd(const gan_conv_geom* g, const float* x, const float* w, const float* bias,
                    float* y, void* ws, size_t ws_bytes, gan_stream_t stream);
+/* gan_conv2d_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The split-K
+ * slabs live in a 64 MiB device array built into the library (one copy per GPU the library runs on, held
+ * until the process ends) instead of a caller workspace; the call itself allocates and frees nothing.
+ * Results are bit-identical to gan_conv2d_fwd with the same plan.  A geometry whose slabs need more than
+ * 64 MiB is refused with an error (use gan_conv2d_fwd).  All calls on one GPU share that GPU's array:
+ * calls that may overlap on one GPU (different streams, different host threads) race and must be
+ * serialised by the caller.  The first call on each device looks the array's address up and should be
+ * made outside graph capture. */
+int gan_conv2d_fwd_static_ws(const gan_conv_geom* g, const float* x, const float* w, const float* bias,
+                             float* y, gan_stream_t stream);
 /* dx[big] = Conv2DBackpropInput(dy[small], w) */
 int gan_conv2d_dgrad(const gan_conv_geom* g, const float* dy, const float* w, float* dx,
                      void* ws, size_t ws_bytes, gan_stream_t stream);
