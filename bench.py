@@ -106,8 +106,15 @@ class ContractionRecorder(ContractionTimer):
         is_conv = name in self.CONV
 
         def call(*args):
-            flops = conv_flops(args[0]._obj) if is_conv else 2.0 * args[0] * args[1] * args[2]
-            self.records.append((fn, args, flops))
+            if is_conv:
+                g = args[0]._obj
+                flops = conv_flops(g)
+                nbytes = 4.0 * (g.n * g.hb * g.wb * g.cb + g.n * g.hs * g.ws * g.cs + g.kh * g.kw * g.cb * g.cs)
+            else:
+                rows, i, o = args[:3]
+                flops = 2.0 * rows * i * o
+                nbytes = 4.0 * (rows * i + rows * o + i * o)
+            self.records.append((fn, args, flops, nbytes))
             return fn(*args)
         return call
 
@@ -116,7 +123,8 @@ def contraction_sequence_time(model, batch, L, replays=20):
     """Duration of the contraction launches of ONE iteration with nothing in between: the iteration is
     captured once (never replayed) with every contraction call recorded; its buffers stay reserved in that
     graph's memory pool, so the recorded calls are issued again, alone, into a second graph, which is
-    replayed `replays` times between two HIP events.  Returns (ms per iteration, FLOP per iteration, calls)."""
+    replayed `replays` times between two HIP events.  Returns (ms per iteration, FLOP per iteration, calls,
+    algorithmic bytes per iteration = every call's two operands and its output once)."""
     from gan_amd._lib import stream
     holder = torch.cuda.CUDAGraph()
     with ContractionRecorder(L) as rec:
@@ -124,7 +132,7 @@ def contraction_sequence_time(model, batch, L, replays=20):
             model.train_iteration(*batch)
     only = torch.cuda.CUDAGraph()
     with torch.cuda.graph(only):
-        for fn, args, _ in rec.records:
+        for fn, args, _, _ in rec.records:
             rc = fn(*(tuple(args[:-1]) + (stream(),)))         # the stream is every entry point's last argument
             if rc != 0:
                 raise SystemExit("re-issuing a recorded contraction call failed: %s" % L.lib.gan_last_error().decode())
@@ -138,7 +146,7 @@ def contraction_sequence_time(model, batch, L, replays=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / replays
     del only, holder
-    return ms, sum(r[2] for r in rec.records), len(rec.records)
+    return ms, sum(r[2] for r in rec.records), len(rec.records), sum(r[3] for r in rec.records)
 
 
 def cpu_baseline(iters):
@@ -163,6 +171,43 @@ def cpu_baseline(iters):
     return {"value": round(BATCH * iters / dt, 3), "unit": "images/s", "cores": int(threads), "kind": "port",
             "sample": "%d iterations of the numpy oracle's DCGAN-64 step (batch 64, fp32, BLAS threads = cores), "
                       "CPU restatement, not TensorFlow" % iters}
+
+
+def committed_traffic(skip):
+    """HBM-side bytes of the contraction launches of one step, from the committed rocprofv3 counter passes
+    (profiles/r02_traffic.json: FETCH_SIZE with the gfx950 doubling + WRITE_SIZE, summed over the same
+    launches `roofline.achieved` is timed on).  Counters cannot be read from inside this process, so the figure
+    is the committed one, valid for the default arithmetic at batch 64 only."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if skip or not os.path.exists(path):
+        return None, "no committed counter pass for this configuration"
+    t = json.load(open(path))
+    return (int(t["read_bytes_per_iteration"] + t["written_bytes_per_iteration"]),
+            "profiles/r02_traffic.md (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE over tools/traffic_probe.py): "
+            "%.2f GB read + %.2f GB written per step" % (t["read_bytes_per_iteration"] / 1e9, t["written_bytes_per_iteration"] / 1e9))
+
+
+def exact_f32_step_ms(model, pool, _lib, steps=10):
+    """The same step with every contraction on the fp32 MFMA (bitwise an fmaf chain per output element):
+    a second captured iteration, timed like the first.  Workspace sizes follow the plans, so one eager
+    iteration runs before the capture."""
+    from gan_amd import ops
+    _lib.lib.gan_set_exact_f32(1)
+    try:
+        ops._ws_cache.clear()
+        model.train_iteration(*pool[0])
+        run = model.iteration_runner(pool[0][0], pool[0][1])
+        for i in range(3):
+            run(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        _lib.lib.gan_set_exact_f32(0)
+        ops._ws_cache.clear()
 
 
 def launch_ranks(n, backend):
@@ -308,6 +353,7 @@ def main():
     # roofline of the dominant kernel family (the MFMA implicit-GEMM contractions), measured live with
     # HIP events around every contraction call of eager iterations (graph replay hides single launches)
     roof = None
+    alg_bytes = None
     timer_iters = 3
     with ContractionTimer(_lib) as tm:
         for i in range(timer_iters):
@@ -318,18 +364,21 @@ def main():
     if world == 1 and pg is None:
         # one GPU: the same launches replayed back to back as a HIP graph (no host dispatch gap between a
         # contraction kernel and its slab reduction), which is how they run in the timed region
-        seq_ms, seq_flops, seq_calls = contraction_sequence_time(model, pool[0], _lib)
+        seq_ms, seq_flops, seq_calls, alg_bytes = contraction_sequence_time(model, pool[0], _lib)
         ms, flops, calls, timer_iters = seq_ms, seq_flops, seq_calls, 1
         method = ("HIP events around 20 replays of a HIP graph holding only the %d contraction calls of one iteration, "
                   "on the buffers of a captured iteration" % seq_calls)
     achieved = flops / (ms * 1e-3) / 1e12
     exact = bool(_lib.lib.gan_get_exact_f32())
+    traffic, traffic_note = committed_traffic(exact or BATCH != nominal_batch or alg_bytes is None)
     # `achieved` counts the ALGORITHMIC fp32 FLOP of the convolutions.  The default arithmetic forms every
     # fp32 product from six bf16 x bf16 part products on the bf16 matrix pipe, so the MFMA ceiling for
     # algorithmic FLOP is the bf16 peak / 6; with --exact-f32 it is the fp32 MFMA peak.
     peak = FP32_MFMA_PEAK_TFLOPS if exact else BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per step, all contraction launches",
+            "traffic_source": traffic_note,
+            "algorithmic_bytes": alg_bytes,
             "kernel": ("igemm_kernel" if exact else "igemm_split_kernel") +
                       " (+ reduce_slabs_kernel) over the %d contraction calls of one iteration" % (calls // timer_iters),
             "arithmetic": ("fp32 MFMA" if exact else
@@ -365,6 +414,8 @@ def main():
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / peak, 4),
             "losses_last_step": {k: round(v, 5) for k, v in losses.items()},
         }
+        if world == 1 and pg is None and not args.exact_f32 and not args.no_graph:
+            line["exact_f32_ms_per_step"] = round(exact_f32_step_ms(model, pool, _lib), 4)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_iters)
         sys.stdout.flush()

@@ -1,0 +1,60 @@
+"""Generates tests/golden/dcgan64_traj200.npz: the float64 numpy oracle's loss trajectory over 200
+iterations of the benchmarked configuration (DCGAN 64x64x3, batch 64, gf_dim = df_dim = 64, lr 2e-4,
+beta1 0.5; one D update + two G updates per iteration, models/dcgan.py:226-279 of the reference).
+
+Only the 200 x 3 losses and the seeds are stored: the initial weights come from the oracle's seeded
+initialisers (rounded to float32, so that the GPU side starts from the very same numbers) and every
+iteration's images and z are drawn from one seeded generator, exactly as the test that replays the
+trajectory draws them.  The reference ships no fixture and TensorFlow 1.x cannot run here: like the
+other files of this directory this pins the ORACLE.  About half an hour on 8 cores:
+    python tests/golden/make_dcgan64_traj.py [iterations]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import autodiff as A          # noqa: E402
+from oracle import nets                   # noqa: E402
+
+WEIGHT_SEED, DATA_SEED, BATCH = 5, 64064, 64
+
+
+def initial_oracle(dtype=np.float64):
+    st = A.Store(seed=WEIGHT_SEED, dtype=dtype)
+    net = nets.DCGAN(st, batch_size=BATCH)
+    net.build(np.zeros((BATCH, 64, 64, 3)), np.zeros((BATCH, 100)))
+    for n in st.values:
+        st.values[n] = st.values[n].astype(np.float32).astype(dtype)
+    return st, net
+
+
+def draw(rng):
+    im = rng.uniform(-1, 1, (BATCH, 64, 64, 3)).astype(np.float32)
+    z = rng.uniform(-1, 1, (BATCH, 100)).astype(np.float32)
+    return im, z
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    st, net = initial_oracle()
+    rng = np.random.default_rng(DATA_SEED)
+    losses = np.zeros((iters, 3))
+    t0 = time.time()
+    for it in range(iters):
+        im, z = draw(rng)
+        out = net.train_iteration(im.astype(np.float64), z.astype(np.float64))
+        losses[it] = (out['d_loss'], out['g_loss_1'], out['g_loss_2'])
+        if it % 10 == 0 or it == iters - 1:
+            print("iteration %d  d_loss %.6f  g_loss %.6f %.6f  (%.0f s)" % ((it,) + tuple(losses[it]) + (time.time() - t0,)),
+                  flush=True)
+    np.savez(os.path.join(HERE, "dcgan64_traj%d.npz" % iters), losses=losses, columns=np.array(['d_loss', 'g_loss_1', 'g_loss_2']),
+             weight_seed=WEIGHT_SEED, data_seed=DATA_SEED, batch=BATCH)
+
+
+if __name__ == "__main__":
+    main()

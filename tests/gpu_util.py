@@ -5,10 +5,15 @@ import os
 import numpy as np
 import torch
 
-# Parity bar for floating point (north_star: "per-op fp32 outputs and gradients within rel 1e-4"):
-# the largest absolute deviation from the float64 oracle, relative to the largest magnitude of the
-# oracle tensor, must not exceed REL_TOL.
+# Parity bar for floating point (north_star: "per-op fp32 outputs and gradients within rel 1e-4"), two
+# conditions on the deviation from the float64 oracle:
+#   max-norm:     max |gpu - ref| <= REL_TOL * max |ref|
+#   elementwise:  |gpu_i - ref_i| <= REL_TOL * |ref_i| + ELEM_FLOOR * REL_TOL * max |ref|   for every i
+# The second one holds every element to 1e-4 of ITSELF; its absolute term (1e-6 of the tensor's largest
+# magnitude at the default tolerance) is what float32 accumulation of a long, cancelling sum leaves on an
+# element whose exact value is near zero.
 REL_TOL = 1e-4
+ELEM_FLOOR = 1e-2
 
 
 def dev(a):
@@ -19,14 +24,21 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def assert_close(got, ref, what="", tol=REL_TOL):
+def assert_close(got, ref, what="", tol=REL_TOL, elementwise=True):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, "%s: shape %s vs oracle %s" % (what, got.shape, ref.shape)
     assert np.isfinite(got).all(), "%s: non-finite values" % what
     scale = max(float(np.abs(ref).max()), 1e-30)
-    err = float(np.abs(got - ref).max()) / scale
+    diff = np.abs(got - ref)
+    err = float(diff.max()) / scale
     assert err <= tol, "%s: max |gpu - oracle| / max |oracle| = %.3e > %.1e" % (what, err, tol)
+    if elementwise:
+        excess = diff - (tol * np.abs(ref) + ELEM_FLOOR * tol * scale)
+        worst = int(np.argmax(excess))
+        assert excess.flat[worst] <= 0, (
+            "%s: element %d: |gpu - oracle| = %.3e exceeds %.1e * |oracle| (%.3e) + %.1e * max |oracle| (%.3e)"
+            % (what, worst, diff.flat[worst], tol, abs(ref.flat[worst]), ELEM_FLOOR * tol, scale))
     return err
 
 
@@ -36,7 +48,11 @@ def check_group_grads(group, ref_grads, tol=3e-4):
     A bias that feeds a batch norm has an exactly-zero true gradient (the normalisation removes any
     per-channel shift), so both sides hold only the rounding noise of a long sum.  Such a gradient is
     recognised by being tiny next to the gradient of the weight it belongs to, and is then only
-    required to be tiny on the GPU side too."""
+    required to be tiny on the GPU side too.
+
+    Gradients that have passed through a whole network are held to the max-norm bar only: an element of,
+    say, a first-layer filter gradient is a sum over 10^5 .. 10^6 cancelling terms, so its own magnitude
+    says nothing about the rounding error it carries."""
     got_all = {v.name: host(v.grad) for v in group.variables}
     for name, got in got_all.items():
         ref = ref_grads[name]
@@ -47,7 +63,7 @@ def check_group_grads(group, ref_grads, tol=3e-4):
             if float(np.abs(ref).max()) < 2e-3 * wscale:
                 assert float(np.abs(got).max()) < 2e-3 * wscale, "grad %s should vanish" % name
                 continue
-        assert_close(got, ref, "grad " + name, tol=tol)
+        assert_close(got, ref, "grad " + name, tol=tol, elementwise=False)
 
 
 def is_noise_grad(name, ref_grads):

@@ -107,20 +107,54 @@ def test_mnist_conditional_dcgan_full_size_against_oracle():
             assert abs(got[k_] - want[k_]) <= 2e-3 * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
 
 
+class _lrelu_recorder(object):
+    """Records the output of every leaky-relu the discriminator applies on the GPU side (the stand-alone one
+    behind d_h0_conv and the ones fused into the batch norms), in call order."""
+
+    def __enter__(self):
+        import gan_amd.dcgan as D
+        from gan_amd import ops
+        self.outputs = []
+        self.saved = (D.lrelu, ops.batch_norm.__call__)
+        rec = self.outputs
+
+        def lrelu(x, *a, **k):
+            y = self.saved[0](x, *a, **k)
+            rec.append(y)
+            return y
+
+        def bn_call(bn, x, *a, **k):
+            y = self.saved[1](bn, x, *a, **k)
+            if k.get('act') == 'lrelu':
+                rec.append(y)
+            return y
+        D.lrelu, ops.batch_norm.__call__ = lrelu, bn_call
+        return self
+
+    def __exit__(self, *exc):
+        import gan_amd.dcgan as D
+        from gan_amd import ops
+        D.lrelu, ops.batch_norm.__call__ = self.saved
+
+
 def test_dcgan64_full_size_against_oracle():
     """BASELINE config 1, the benchmarked one: DCGAN 64x64x3, batch 64, gf_dim = df_dim = 64, default
     contraction arithmetic.  The D update's gradients of the first iteration and the losses of two whole
     iterations (1 D + 2 G updates each) against the float64 oracle.
 
-    Gradient bars: the layers above the last leaky-relu whose 10^5..10^6 units include one within float32
-    rounding of its kink (d_h3_lin, d_bn3, d_h3_conv, d_bn2/gamma here) agree to 1e-5.  Below such a unit
-    every float32 evaluation -- this library in either arithmetic mode and the oracle run in float32 alike,
-    measured 8e-4 .. 8e-3 on these very inputs -- differs from float64 by the gradient that one unit
-    switches, so the lower layers are held to 2e-2; biases that feed a batch norm are noise on both sides."""
+    A leaky-relu's derivative jumps at 0, and among the 1.6e7 units of the two discriminator passes a few
+    hundred sit within float32 rounding of the kink: there any float32 evaluation may take the other branch
+    than float64 does, and each such unit changes the gradients below it by the whole gradient it switches.
+    The units whose float64 pre-activation lies within 2e-5 of the kink are therefore masked on both sides:
+    the oracle's backward pass takes the branch the GPU took there (read back from the GPU's activations; the
+    forward values are untouched).  With them out of the way every gradient of the discriminator is held to
+    3e-4 (max-norm) and the layers above the last leaky-relu to 1e-5; biases that feed a batch norm are noise
+    on both sides."""
     from oracle import autodiff as A
     from oracle import nets
+    from oracle import tf_ops as T
     from gan_amd.dcgan import DCGAN
-    from gpu_util import check_group_grads, dev
+    from gpu_util import check_group_grads, dev, host
     opts = argparse.Namespace(model='DCGAN', dataset='celebA', batch_size=64, input_height=108, input_width=108,
                               output_height=64, output_width=64, y_dim=None, z_dim=100, gf_dim=64, df_dim=64,
                               gfc_dim=1024, dfc_dim=1024, c_dim=3, lr=0.0002, beta1=0.5, crop=True, nEpochs=1,
@@ -136,19 +170,40 @@ def test_dcgan64_full_size_against_oracle():
     rng = np.random.default_rng(5)
     im = rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)
     z = rng.uniform(-1, 1, (64, 100)).astype(np.float32)
-    # gradients of d_loss w.r.t. d_vars at the initial weights
-    tp = A.Tape(ref.st)
-    lr_, lf_ = ref.d_losses(tp, im.astype(np.float64), z.astype(np.float64))
-    tp.backward(A.add(tp, lr_, lf_))
-    gpu.d_grads(dev(im), dev(z))
+    # gradients of d_loss w.r.t. d_vars at the initial weights: GPU first, recording its leaky-relu outputs
+    with _lrelu_recorder() as rec:
+        gpu.d_grads(dev(im), dev(z))
     torch.cuda.synchronize()
+    assert gpu.stack_d_passes and len(rec.outputs) == 4           # h0..h3 of the stacked (real; fake) batch
+    gpu_act = [host(t) for t in rec.outputs]
+    margin, calls, masked = 2e-5, [0], [0]
+    plain_lrelu = A.lrelu
+
+    def lrelu_following_the_gpu_near_the_kink(tp, x, leak=0.2):
+        i = calls[0]
+        calls[0] += 1
+        half = gpu_act[i % 4][(i // 4) * 64:(i // 4 + 1) * 64]    # the oracle runs D(real) then D(fake)
+        assert half.shape == x.v.shape
+        near = np.abs(x.v) < margin
+        masked[0] += int(near.sum())
+        upper = np.where(near, half >= 0, x.v >= 0)
+        return tp.op(T.lrelu(x.v, leak), [x], lambda g: x.accumulate(np.where(upper, g, x.v.dtype.type(leak) * g)))
+    tp = A.Tape(ref.st)
+    A.lrelu = lrelu_following_the_gpu_near_the_kink
+    try:
+        lr_, lf_ = ref.d_losses(tp, im.astype(np.float64), z.astype(np.float64))
+    finally:
+        A.lrelu = plain_lrelu
+    assert calls[0] == 8
+    tp.backward(A.add(tp, lr_, lf_))
     want_g = tp.grads(ref.d_vars)
-    check_group_grads(gpu.d_group, want_g, tol=2e-2)
-    top = ('d_h3_lin/Matrix', 'd_h3_lin/bias', 'd_bn3/beta', 'd_bn3/gamma', 'd_h3_conv/w', 'd_bn2/gamma')
+    print("units masked at the leaky-relu kink: %d of %d" % (masked[0], sum(a.size for a in gpu_act)))
+    check_group_grads(gpu.d_group, want_g, tol=3e-4)
+    top = ('d_h3_lin/Matrix', 'd_h3_lin/bias', 'd_bn3/beta', 'd_bn3/gamma')
     for v in gpu.d_group.variables:
         if v.name.split('/', 1)[1] in top:
-            from gpu_util import assert_close, host
-            assert_close(host(v.grad), want_g[v.name], "grad " + v.name, tol=1e-5)
+            from gpu_util import assert_close
+            assert_close(host(v.grad), want_g[v.name], "grad " + v.name, tol=1e-5, elementwise=False)
     for it in range(2):
         want = ref.train_iteration(im.astype(np.float64), z.astype(np.float64))
         out = gpu.train_iteration(dev(im), dev(z))
@@ -156,12 +211,60 @@ def test_dcgan64_full_size_against_oracle():
                'g_loss_1': float(out['g_loss_1']), 'g_loss_2': float(out['g_loss_2'])}
         # stated tolerance: 2e-3 on the first iteration's losses, 1e-2 on the second's (Adam's first steps move
         # every weight by about lr whatever the size of its gradient, which amplifies the float32 differences
-        # of the first iteration; the 200-step trajectory test bounds the growth)
+        # of the first iteration; the 200-step trajectory tests bound the growth)
         tol = 2e-3 if it == 0 else 1e-2
         for k_ in got:
             assert abs(got[k_] - want[k_]) <= tol * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
         im = rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)
         z = rng.uniform(-1, 1, (64, 100)).astype(np.float32)
+
+
+def test_dcgan64_full_size_loss_trajectory_200_steps():
+    """The benchmarked configuration over 200 iterations (1 D + 2 G updates each, models/dcgan.py:226-279)
+    against the committed float64-oracle trajectory tests/golden/dcgan64_traj200.npz (generator script
+    alongside: same weight seed, same data generator, so only losses and seeds are stored).
+
+    Stated tolerance: |loss - float64 oracle| <= 2e-2 over the first 20 iterations and <= 1e-1 over all 200,
+    for each of d_loss, g_loss (first update), g_loss (second update).  Training amplifies rounding (Adam
+    turns near-zero gradients into +-lr steps, relu / leaky-relu units at their kink flip), which is why the
+    bar widens with the iteration count; the float32 numpy oracle's own drift is of the same size
+    (test_gpu_dcgan.test_schedule_and_loss_trajectory_200_steps measures both side by side at a small size)."""
+    import os
+    import sys
+    from gan_amd.dcgan import DCGAN
+    from gpu_util import dev
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    try:
+        import make_dcgan64_traj as M
+    finally:
+        sys.path.remove(here)
+    gold = np.load(os.path.join(here, "dcgan64_traj200.npz"))
+    assert int(gold['weight_seed']) == M.WEIGHT_SEED and int(gold['data_seed']) == M.DATA_SEED and int(gold['batch']) == 64
+    want = gold['losses']
+    st, _ = M.initial_oracle()
+    opts = argparse.Namespace(model='DCGAN', dataset='celebA', batch_size=64, input_height=108, input_width=108,
+                              output_height=64, output_width=64, y_dim=None, z_dim=100, gf_dim=64, df_dim=64,
+                              gfc_dim=1024, dfc_dim=1024, c_dim=3, lr=0.0002, beta1=0.5, crop=True, nEpochs=1,
+                              train_size=1e8, print_every=1, checkpoint_dir='./checkpoint', seed=0)
+    gpu = DCGAN(None, opts, load_data=False)
+    assert list(gpu.store.vars) == list(st.values)
+    gpu.store.load_state_dict(st.values)
+    rng = np.random.default_rng(M.DATA_SEED)
+    outs = []
+    for it in range(want.shape[0]):
+        im, z = M.draw(rng)
+        outs.append(gpu.train_iteration(dev(im), dev(z)))           # losses stay on the device until the end
+    torch.cuda.synchronize()
+    got = np.array([[float(o['d_loss_real']) + float(o['d_loss_fake']), float(o['g_loss_1']), float(o['g_loss_2'])]
+                    for o in outs])
+    assert np.isfinite(got).all()
+    dev_ = np.abs(got - want).max(axis=1)
+    print("max |loss - float64 oracle| over 20 / 200 iterations at DCGAN-64, batch 64: %.3e / %.3e"
+          % (dev_[:20].max(), dev_.max()))
+    assert gpu.d_optim.steps_taken == 200 and gpu.g_optim.steps_taken == 400
+    assert dev_[:20].max() <= 2e-2
+    assert dev_.max() <= 1e-1
 
 
 def _finite_grads(optims):

@@ -678,4 +678,4 @@ def test_weight_and_bias_gradient_of_unaligned_views(L):
     ref_db = host(dy0.view(-1, 256).double().sum(0))
     for dw, db in outs:
         assert_close(db, ref_db, "bias gradient", tol=1e-5)
-    assert_close(outs[1][0], outs[0][0], "weight gradient of the unaligned views", tol=1e-5)
+    assert_close(outs[1][0], outs[0][0], "weight gradient of the unaligned views")

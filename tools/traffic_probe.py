@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Program for the HBM-traffic passes of the contraction family (run under `rocprofv3 --pmc ...`, one counter
+set per run; summarised by tools/traffic_summary.py):
+
+  1. calibration: a 512 MiB and a 16 MiB device-to-device copy of known size (16 bytes per lane, the access
+     shape of the contraction kernels' loads, slab stores and slab reductions);
+  2. the 62 conv / deconv / linear C-ABI calls of one DCGAN-64 iteration (batch 64), replayed alone as a HIP
+     graph on the buffers of a captured iteration -- the launches bench.py's `roofline.achieved` is timed on --
+     `--replays` times between two marker triples (three 3-element gan_fill launches in a row).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import bench  # noqa: E402
+from gan_amd import _lib, autotune  # noqa: E402
+from gan_amd._lib import stream  # noqa: E402
+from gan_amd.dcgan import DCGAN  # noqa: E402
+
+
+def marker(buf):
+    for _ in range(3):
+        _lib.check(_lib.lib.gan_fill(buf.data_ptr(), 3, 1.0, stream()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replays", type=int, default=3)
+    ap.add_argument("--no-autotune", action="store_true")
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    mark = torch.zeros(4, device='cuda')
+    big_a = torch.randn(128 << 20, device='cuda')          # 512 MiB of fp32
+    big_b = torch.empty_like(big_a)
+    small_a, small_b = torch.randn(4 << 20, device='cuda'), torch.empty(4 << 20, device='cuda')
+    torch.cuda.synchronize()
+    marker(mark)
+    big_b.copy_(big_a)
+    small_b.copy_(small_a)
+    marker(mark)
+    torch.cuda.synchronize()
+    del big_a, big_b
+
+    autotune.enable(not args.no_autotune)
+    model = DCGAN(None, bench.dcgan64_opts(seed=0), load_data=False)
+    rng = np.random.default_rng(1000)
+    im = torch.from_numpy(rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)).cuda()
+    z = torch.from_numpy(rng.uniform(-1, 1, (64, 100)).astype(np.float32)).cuda()
+    for _ in range(2):
+        model.train_iteration(im, z)
+    torch.cuda.synchronize()
+    holder = torch.cuda.CUDAGraph()
+    with bench.ContractionRecorder(_lib) as rec:
+        with torch.cuda.graph(holder):
+            model.train_iteration(im, z)
+    only = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(only):
+        for fn, a, _, _ in rec.records:
+            _lib.check(fn(*(tuple(a[:-1]) + (stream(),))))
+    only.replay()
+    torch.cuda.synchronize()
+    marker(mark)
+    for _ in range(args.replays):
+        only.replay()
+    marker(mark)
+    torch.cuda.synchronize()
+    flops = sum(r[2] for r in rec.records)
+    print("contraction calls per iteration: %d, nominal GFLOP per iteration: %.2f, replays: %d"
+          % (len(rec.records), flops / 1e9, args.replays), flush=True)
+
+
+if __name__ == "__main__":
+    main()
