@@ -260,6 +260,8 @@ def main():
                     help="images per GPU per step; 64 is the benchmark's configuration, other values are for exploration "
                          "and are named in config.workload")
     ap.add_argument("--detail", action="store_true", help="also print the per-call contraction timing table to stderr")
+    ap.add_argument("--no-exact-f32-time", action="store_true",
+                    help="skip the second captured iteration that times the step on the fp32 MFMA (exact_f32_ms_per_step)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the multi-rank launch: the ranks join the group, count each other with an "
                          "all-reduce and rank 0 prints {\"launch_check\": true, \"n_ranks_seen\": N}; no GPU work")
@@ -414,7 +416,7 @@ def main():
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / peak, 4),
             "losses_last_step": {k: round(v, 5) for k, v in losses.items()},
         }
-        if world == 1 and pg is None and not args.exact_f32 and not args.no_graph:
+        if world == 1 and pg is None and not args.exact_f32 and not args.no_graph and not args.no_exact_f32_time:
             line["exact_f32_ms_per_step"] = round(exact_f32_step_ms(model, pool, _lib), 4)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_iters)

@@ -39,19 +39,41 @@ def draw(rng):
     return im, z
 
 
+def _state(st, net, rng, losses, done):
+    return {'values': st.values, 'adam': [(a.t, a.m, a.v) for a in (net.d_adam, net.g_adam)],
+            'rng': rng.bit_generator.state, 'losses': losses, 'done': done}
+
+
 def main():
+    """A run that is interrupted resumes from the state it last left under /tmp (every 10 iterations)."""
+    import pickle
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    ckpt = "/tmp/dcgan64_traj_state_%d.pkl" % iters
     st, net = initial_oracle()
     rng = np.random.default_rng(DATA_SEED)
     losses = np.zeros((iters, 3))
+    first = 0
+    if os.path.exists(ckpt):
+        with open(ckpt, "rb") as f:
+            s = pickle.load(f)
+        st.values.update(s['values'])
+        for a, (t, m, v) in zip((net.d_adam, net.g_adam), s['adam']):
+            a.t, a.m, a.v = t, m, v
+        rng.bit_generator.state = s['rng']
+        losses, first = s['losses'], s['done']
+        print("resuming after iteration %d" % first, flush=True)
     t0 = time.time()
-    for it in range(iters):
+    for it in range(first, iters):
         im, z = draw(rng)
         out = net.train_iteration(im.astype(np.float64), z.astype(np.float64))
         losses[it] = (out['d_loss'], out['g_loss_1'], out['g_loss_2'])
         if it % 10 == 0 or it == iters - 1:
             print("iteration %d  d_loss %.6f  g_loss %.6f %.6f  (%.0f s)" % ((it,) + tuple(losses[it]) + (time.time() - t0,)),
                   flush=True)
+        if it % 10 == 9 and it + 1 < iters:
+            with open(ckpt + ".tmp", "wb") as f:
+                pickle.dump(_state(st, net, rng, losses, it + 1), f, protocol=4)
+            os.replace(ckpt + ".tmp", ckpt)
     np.savez(os.path.join(HERE, "dcgan64_traj%d.npz" % iters), losses=losses, columns=np.array(['d_loss', 'g_loss_1', 'g_loss_2']),
              weight_seed=WEIGHT_SEED, data_seed=DATA_SEED, batch=BATCH)
 
