@@ -23,14 +23,24 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
+def marker():
+    """Three 3-element fill launches in a row: brackets the timed region in a kernel trace (tools/trace_summary.py)."""
+    from gan_amd import _lib
+    buf = torch.zeros(4, device='cuda')
+    for _ in range(3):
+        _lib.check(_lib.lib.gan_fill(buf.data_ptr(), 3, 1.0, _lib.stream()))
+
+
 def timed(run, inputs, steps, warmup=3):
     for _ in range(warmup):
         out = run(*inputs)
     torch.cuda.synchronize()
+    marker()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = run(*inputs)
     torch.cuda.synchronize()
+    marker()
     dt = (time.perf_counter() - t0) / steps
     vals = {k: float(v) for k, v in out.items() if getattr(v, "numel", lambda: 0)() == 1}
     assert np.isfinite(list(vals.values())).all(), vals
