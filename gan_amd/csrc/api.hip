@@ -21,6 +21,8 @@ size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                    const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
+int run_igemm_geom_epi(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
+                       const Epilogue& epi, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what);
 // elementwise.hip
 size_t colsum_ws_bytes(long rows, int c);
 int colsum_partial(const float* x, long rows, int c, void* ws, size_t ws_bytes, hipStream_t st, const char* what,
@@ -133,6 +135,53 @@ extern "C" int gan_conv2d_fwd(const gan_conv_geom* g, const float* x, const floa
     if (int rc = conv_geom_check(g)) return rc;
     GAN_CHECK_ARG(x && w && y, "gan_conv2d_fwd: NULL tensor");
     return run_igemm_geom(MODE_FPROP, *g, x, w, y, bias, 0, g->cs, ws, ws_bytes, as_stream(stream), "gan_conv2d_fwd");
+}
+
+// ---------------------------------------------------------------------------- fused activation epilogues
+static int act_check(const char* what, int act, float scale) {
+    GAN_CHECK_ARG(act >= GAN_ACT_NONE && act <= GAN_ACT_SIGMOID, "%s: unknown activation %d", what, act);
+    GAN_CHECK_ARG(scale != 0.f, "%s: activation scale must not be 0", what);
+    return 0;
+}
+
+extern "C" int gan_conv2d_fwd_act(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                                  int act, float act_param, float act_scale, float act_shift, void* ws, size_t ws_bytes,
+                                  gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    if (int rc = act_check("gan_conv2d_fwd_act", act, act_scale)) return rc;
+    GAN_CHECK_ARG(x && w && y, "gan_conv2d_fwd_act: NULL tensor");
+    return run_igemm_geom_epi(MODE_FPROP, *g, x, w, y, bias, Epilogue{act, act_param, act_scale, act_shift, nullptr}, g->cs, ws,
+                              ws_bytes, as_stream(stream), "gan_conv2d_fwd_act");
+}
+
+extern "C" int gan_deconv2d_fwd_act(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                                    int act, float act_param, float act_scale, float act_shift, void* ws, size_t ws_bytes,
+                                    gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    if (int rc = act_check("gan_deconv2d_fwd_act", act, act_scale)) return rc;
+    GAN_CHECK_ARG(x && w && y, "gan_deconv2d_fwd_act: NULL tensor");
+    return run_igemm_geom_epi(MODE_TPROP, *g, x, w, y, bias, Epilogue{act, act_param, act_scale, act_shift, nullptr}, g->cb, ws,
+                              ws_bytes, as_stream(stream), "gan_deconv2d_fwd_act");
+}
+
+extern "C" int gan_conv2d_dgrad_gated(const gan_conv_geom* g, const float* dy, const float* w, float* dx, const float* gate,
+                                      int act, float act_param, float act_scale, float act_shift, void* ws,
+                                      size_t ws_bytes, gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    if (int rc = act_check("gan_conv2d_dgrad_gated", act, act_scale)) return rc;
+    GAN_CHECK_ARG(dy && w && dx && gate, "gan_conv2d_dgrad_gated: NULL tensor");
+    return run_igemm_geom_epi(MODE_TPROP, *g, dy, w, dx, nullptr, Epilogue{act, act_param, act_scale, act_shift, gate}, g->cb,
+                              ws, ws_bytes, as_stream(stream), "gan_conv2d_dgrad_gated");
+}
+
+extern "C" int gan_deconv2d_dgrad_gated(const gan_conv_geom* g, const float* dy, const float* w, float* dx, const float* gate,
+                                        int act, float act_param, float act_scale, float act_shift, void* ws,
+                                        size_t ws_bytes, gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    if (int rc = act_check("gan_deconv2d_dgrad_gated", act, act_scale)) return rc;
+    GAN_CHECK_ARG(dy && w && dx && gate, "gan_deconv2d_dgrad_gated: NULL tensor");
+    return run_igemm_geom_epi(MODE_FPROP, *g, dy, w, dx, nullptr, Epilogue{act, act_param, act_scale, act_shift, gate}, g->cs,
+                              ws, ws_bytes, as_stream(stream), "gan_deconv2d_dgrad_gated");
 }
 
 // ---------------------------------------------------------------------------- entry point that allocates nothing

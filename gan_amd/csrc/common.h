@@ -92,4 +92,33 @@ __device__ __forceinline__ float act_grad(float z, float a, int act, float param
     }
 }
 
+// From a saved output y = act(x)*scale+shift: a = (y-shift)/scale has the sign of x for relu / lrelu and equals
+// tanh(x) / sigmoid(x), which is all the derivative needs.  Returns dy * d y / d x.
+__device__ __forceinline__ float act_bwd_one(float y, float dy, int act, float param, float scale, float shift) {
+    const float a = (scale == 1.f && shift == 0.f) ? y : (y - shift) / scale;
+    return dy * scale * act_grad(a, a, act, param);
+}
+
+// What a contraction does to a finished output element v (bias already added) before storing it:
+//   gate == nullptr:  v <- act(v) * scale + shift            (activation fused behind conv / deconv)
+//   gate != nullptr:  v <- v * d act / d x at gate[same index] (the output is the gradient w.r.t. an activated tensor
+//                     `gate` = act(x)*scale+shift; the stored value is the gradient w.r.t. x)
+// act == GAN_ACT_NONE with scale 1, shift 0 and no gate is the identity.
+struct Epilogue {
+    int act;
+    float param, scale, shift;
+    const float* gate;
+};
+
+__device__ __forceinline__ bool epi_active(const Epilogue& e) {
+    return e.gate != nullptr || e.act != GAN_ACT_NONE || e.scale != 1.f || e.shift != 0.f;
+}
+
+__device__ __forceinline__ float epi_apply(const Epilogue& e, float v, long idx) {
+    if (e.gate != nullptr) return act_bwd_one(e.gate[idx], v, e.act, e.param, e.scale, e.shift);
+    return apply_act(v, e.act, e.param) * e.scale + e.shift;
+}
+
+inline Epilogue no_epilogue() { return Epilogue{GAN_ACT_NONE, 0.f, 1.f, 0.f, nullptr}; }
+
 }  // namespace gan

@@ -30,13 +30,6 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
         y[i] = apply_act(x[i], act, param) * scale + shift;
 }
 
-// From the saved output y = act(x)*scale+shift: a = (y-shift)/scale has the sign of x for
-// relu / lrelu and equals tanh(x) / sigmoid(x), which is all the derivative needs.
-__device__ __forceinline__ float act_bwd_one(float y, float dy, int act, float param, float scale, float shift) {
-    const float a = (scale == 1.f && shift == 0.f) ? y : (y - shift) / scale;
-    return dy * scale * act_grad(a, a, act, param);
-}
-
 __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
                                long n, int act, float param, float scale, float shift) {
     const long stride = (long)gridDim.x * blockDim.x;

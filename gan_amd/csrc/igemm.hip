@@ -79,6 +79,7 @@ struct IgemmArgs {
     int ncls;
     FastDiv d_cb, d_cs, d_kw, d_hsws, d_ws;
     ClassInfo cls[kMaxClasses];
+    Epilogue epi;  // applied where the final value is stored: here when splits == 1, else by the slab reduction
 };
 
 // Raw gather load: masked-off lanes read element 0 of the tensor (always mapped); the zeroing
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     float* dst = p.out + (p.splits > 1 ? (long)split * p.slab_elems : 0L);
     const bool direct = p.splits == 1;
     const bool accum = direct && p.accumulate;
+    const bool epi_on = direct && epi_active(p.epi);
 
     if (p.vec_epilogue) {
         // The accumulators sit row-per-register; dword-per-lane stores of them are issue bound.
@@ -474,6 +476,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                         const float4 old = *o;
                         v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                     }
+                    if (epi_on) {
+                        const long e = (long)off + col;
+                        v.x = epi_apply(p.epi, v.x, e); v.y = epi_apply(p.epi, v.y, e + 1);
+                        v.z = epi_apply(p.epi, v.z, e + 2); v.w = epi_apply(p.epi, v.w, e + 3);
+                    }
                     *o = v;
                 }
             }
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 if (ncol[j] < N) {
                     float v = acc[i][j][r] + bias_v[j];
                     if (accum) v += dst[off + ncol[j]];
+                    if (epi_on) v = epi_apply(p.epi, v, (long)off + ncol[j]);
                     dst[off + ncol[j]] = v;
                 }
             }
@@ -514,7 +522,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 // that; any further ones carry the last stage of the bias-gradient column sum (`tail`).
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                     const float* __restrict__ bias, long elems, int c, int splits,
-                                    int accumulate, int own_blocks, const ColsumFinal tail) {
+                                    int accumulate, int own_blocks, const ColsumFinal tail, const Epilogue epi) {
+    const bool epi_on = epi_active(epi);
     if ((int)blockIdx.x >= own_blocks) {
         colsum_final_block(tail, blockIdx.x - own_blocks);
         return;
@@ -536,6 +545,10 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
                 const float4 o = reinterpret_cast<const float4*>(out)[i];
                 s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
             }
+            if (epi_on) {
+                s.x = epi_apply(epi, s.x, i * 4); s.y = epi_apply(epi, s.y, i * 4 + 1);
+                s.z = epi_apply(epi, s.z, i * 4 + 2); s.w = epi_apply(epi, s.w, i * 4 + 3);
+            }
             reinterpret_cast<float4*>(out)[i] = s;
         }
     } else {
@@ -544,6 +557,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
             for (int k = 1; k < splits; ++k) s += slabs[(long)k * elems + i];
             if (bias) s += bias[(int)(i % c)];
             if (accumulate) s += out[i];
+            if (epi_on) s = epi_apply(epi, s, i);
             out[i] = s;
         }
     }
@@ -555,7 +569,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 const float* __restrict__ bias, long elems, int c,
                                                                 int splits, int accumulate, int own_blocks,
-                                                                const ColsumFinal tail) {
+                                                                const ColsumFinal tail, const Epilogue epi) {
     __shared__ float4 red[16][16];
     if ((int)blockIdx.x >= own_blocks) {          // (uniform per workgroup: no barrier is skipped by part of one)
         colsum_final_block(tail, blockIdx.x - own_blocks);
@@ -588,6 +602,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
             const float4 o = reinterpret_cast<const float4*>(out)[i4];
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
+        if (epi_active(epi)) {
+            s.x = epi_apply(epi, s.x, i4 * 4); s.y = epi_apply(epi, s.y, i4 * 4 + 1);
+            s.z = epi_apply(epi, s.z, i4 * 4 + 2); s.w = epi_apply(epi, s.w, i4 * 4 + 3);
+        }
         reinterpret_cast<float4*>(out)[i4] = s;
     }
 }
@@ -612,6 +630,7 @@ struct ThinArgs {
     const float* bias;  // [cb] or null
     int ncls, tiles_h, tiles_w;
     ClassInfo cls[kMaxClasses];
+    Epilogue epi;
 };
 
 // MAXT bounds the taps per axis of any class and sizes the LDS halo (3: 5x5 stride 2 -> 27 KB, five
@@ -678,8 +697,13 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
     if (qh < cl.hq && qw < cl.wq) {
         const int h = (cl.hq0 + qh) * g.sh + cl.ph - g.pt, w = (cl.wq0 + qw) * g.sw + cl.pw - g.pl;
         float* o = p.out + (((long)img * g.hb + h) * g.wb + w) * g.cb;
+        const bool epi_on = epi_active(p.epi);
 #pragma unroll
-        for (int c = 0; c < CB; ++c) o[c] = acc[c] + (p.bias ? p.bias[c] : 0.f);
+        for (int c = 0; c < CB; ++c) {
+            float v = acc[c] + (p.bias ? p.bias[c] : 0.f);
+            if (epi_on) v = epi_apply(p.epi, v, (o - p.out) + c);
+            o[c] = v;
+        }
     }
 }
 
@@ -882,6 +906,7 @@ static int run_thin_tprop(const IgemmArgs& a, hipStream_t s, const char* what) {
     ThinArgs t;
     t.g = a.g;
     t.in = a.a; t.w = a.b; t.out = a.out; t.bias = a.bias;
+    t.epi = a.epi;
     t.ncls = a.ncls;
     int hq = 0, wq = 0;
     for (int i = 0; i < kMaxClasses; ++i) {
@@ -994,7 +1019,7 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         const long n4 = pl.out_elems >> 2;
         const int own = (int)((n4 + 15) / 16);
         hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)(own + job.blocks)), dim3(256), 0, s,
-                           static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, own, job);
+                           static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, own, job, a.epi);
         if (int rc = check_launch(what)) return rc;
         if (job.blocks > 0) *tail_done = 1;
     } else if (pl.splits > 1) {
@@ -1003,7 +1028,7 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks + job.blocks), dim3(256), 0, s, static_cast<const float*>(ws),
-                           final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, blocks, job);
+                           final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, blocks, job, a.epi);
         if (int rc = check_launch(what)) return rc;
         if (job.blocks > 0) *tail_done = 1;
     }
@@ -1028,6 +1053,7 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.a = a; r.b = b; r.out = out; r.bias = bias;
     r.accumulate = accumulate;
     r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1; r.vec_epilogue = 0;
+    r.epi = no_epilogue();
     r.d_cb = make_fastdiv((unsigned)g.cb);
     r.d_cs = make_fastdiv((unsigned)g.cs);
     r.d_kw = make_fastdiv((unsigned)g.kw);
@@ -1096,6 +1122,14 @@ int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                    const ColsumFinal* tail, int* tail_done) {
     return run_igemm(mode, make_args(mode, g, a, b, out, bias, accumulate), out_c, ws, ws_bytes, s, what, tail, tail_done);
+}
+
+// The same with a fused epilogue (activation behind the output, or the activation derivative of a gate tensor).
+int run_igemm_geom_epi(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
+                       const Epilogue& epi, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what) {
+    IgemmArgs args = make_args(mode, g, a, b, out, bias, 0);
+    args.epi = epi;
+    return run_igemm(mode, args, out_c, ws, ws_bytes, s, what, nullptr, nullptr);
 }
 
 }  // namespace gan

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     float* dst = p.out + (p.splits > 1 ? (long)split * p.slab_elems : 0L);
     const bool direct = p.splits == 1;
     const bool accum = direct && p.accumulate;
+    const bool epi_on = direct && epi_active(p.epi);
 
     int tcol[TN];  // tile column of this lane's accumulator column j
 #pragma unroll
@@ -490,6 +491,11 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
                         const float4 old = *o;
                         v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                     }
+                    if (epi_on) {
+                        const long e = (long)off + col;
+                        v.x = epi_apply(p.epi, v.x, e); v.y = epi_apply(p.epi, v.y, e + 1);
+                        v.z = epi_apply(p.epi, v.z, e + 2); v.w = epi_apply(p.epi, v.w, e + 3);
+                    }
                     *o = v;
                 }
             }
@@ -515,6 +521,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
                 if (col < N) {
                     float v = acc[i][j][r] + bias_v[j];
                     if (accum) v += dst[off + col];
+                    if (epi_on) v = epi_apply(p.epi, v, (long)off + col);
                     dst[off + col] = v;
                 }
             }

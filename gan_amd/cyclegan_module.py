@@ -24,7 +24,7 @@ def discriminator(image, options, reuse=False, name="discriminator"):
         d_bn2 = batch_norm(name='d_bn2')
         d_bn3 = batch_norm(name='d_bn3')
 
-        h0 = lrelu(conv2d(image, options.df_dim, name='d_h0_conv'))
+        h0 = conv2d(image, options.df_dim, name='d_h0_conv', act='lrelu')
         # -> [n, 128, 128, df_dim]
         h1 = d_bn1(conv2d(h0, options.df_dim * 2, name='d_h1_conv'), act='lrelu')
         # -> [n, 64, 64, 2 df_dim]

@@ -145,7 +145,7 @@ class DCGAN(object):
             if reuse:
                 scope.reuse_variables()
             if not self.y_dim:
-                h0 = lrelu(conv2d(image, self.df_dim, name='d_h0_conv'))
+                h0 = conv2d(image, self.df_dim, name='d_h0_conv', act='lrelu')
                 h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)
                 h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)
                 self._note_d_boundary(h2)           # the layers after it own the early part of the d group
@@ -154,7 +154,7 @@ class DCGAN(object):
                 return (_sigmoid_value(h4) if with_prob else None), h4
             yb = y.reshape(bs, 1, 1, self.y_dim)
             x = conv_cond_concat(image, yb)
-            h0 = lrelu(conv2d(x, self.c_dim + self.y_dim, name='d_h0_conv'))
+            h0 = conv2d(x, self.c_dim + self.y_dim, name='d_h0_conv', act='lrelu')
             h0 = conv_cond_concat(h0, yb)
             h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv'), act='lrelu', passes=passes)
             h1 = h1.reshape(bs, -1)
@@ -187,8 +187,8 @@ class DCGAN(object):
                 h2 = self.g_bn2(h2, train=train, act='relu')
                 h3, self.h3_w, self.h3_b = deconv2d(h2, [bs, s_h2, s_w2, self.gf_dim * 1], name='g_h3', with_w=True)
                 h3 = self.g_bn3(h3, train=train, act='relu')
-                h4, self.h4_w, self.h4_b = deconv2d(h3, [bs, s_h, s_w, self.c_dim], name='g_h4', with_w=True)
-                return ops.tanh(h4)
+                h4, self.h4_w, self.h4_b = deconv2d(h3, [bs, s_h, s_w, self.c_dim], name='g_h4', with_w=True, act='tanh')
+                return h4                       # tanh(h4) of dcgan.py:385, applied in the deconv's epilogue
             s_h, s_w = self.output_height, self.output_width
             s_h2, s_h4 = int(s_h / 2), int(s_h / 4)
             s_w2, s_w4 = int(s_w / 2), int(s_w / 4)
@@ -202,7 +202,7 @@ class DCGAN(object):
             self._g_bound = h1
             h2 = self.g_bn2(deconv2d(h1, [bs, s_h2, s_w2, self.gf_dim * 2], name='g_h2'), train=train, act='relu')
             h2 = conv_cond_concat(h2, yb)
-            return ops.sigmoid(deconv2d(h2, [bs, s_h, s_w, self.c_dim], name='g_h3'))
+            return deconv2d(h2, [bs, s_h, s_w, self.c_dim], name='g_h3', act='sigmoid')
 
     def sampler(self, z, y=None):
         """dcgan.py:412-462: the generator with batch-norm in inference mode."""

@@ -126,22 +126,66 @@ def _dense(x):
 # --------------------------------------------------------------------------------------------
 # conv2d / deconv2d / linear
 # --------------------------------------------------------------------------------------------
+class _ActToken(object):
+    """Travels with the output of a conv / deconv whose activation is fused into its epilogue (`act=`).  A conv /
+    deconv that takes that output as its input multiplies the input gradient it produces by the activation's
+    derivative on store (the gated input-gradient entry points) and notes the gradient tensor here; the
+    producing layer's backward then finds its incoming gradient already taken through the activation."""
+    __slots__ = ('spec', 'grad_ptr')
+
+    def __init__(self, spec):
+        self.spec = spec          # (activation code, parameter, scale, shift)
+        self.grad_ptr = None      # data pointer of the gradient a gated consumer produced
+
+
+def _act_spec(act, act_param, act_scale, act_shift):
+    code = ACT_CODES[act]
+    if code == _lib.ACT_NONE and act_scale == 1.0 and act_shift == 0.0:
+        return None
+    return (code, float(act_param), float(act_scale), float(act_shift))
+
+
+def _through_own_activation(ctx, y, dy):
+    """Gradient w.r.t. the contraction output in front of a fused activation, from the gradient w.r.t. the
+    activated output y."""
+    tok = ctx.act_tok
+    if tok.grad_ptr is not None:
+        ptr_, tok.grad_ptr = tok.grad_ptr, None
+        if dy.data_ptr() != ptr_:
+            raise RuntimeError("the output of a conv / deconv with a fused activation feeds a gated consumer AND something "
+                               "else: their gradients were summed after one of them had been taken through the "
+                               "activation; apply the activation as an op of its own (ops.lrelu / tanh / ...) here")
+        return dy                 # the consumer's input-gradient epilogue has applied the derivative
+    code, param, scale, shift = tok.spec
+    dz = torch.empty_like(y)
+    check(lib.gan_act_bwd(ptr(y), ptr(dy), ptr(dz), y.numel(), code, param, scale, shift, stream()))
+    return dz
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, token, w, b, g):
+    def forward(ctx, x, token, w, b, g, act_tok, in_tok):
         x = _dense(x)
         y = torch.empty((g.n, g.hs, g.ws, g.cs), dtype=torch.float32, device=x.device)
         wp, wn = _conv_ws(g)
-        check(lib.gan_conv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
-        ctx.save_for_backward(x)
-        ctx.w, ctx.b, ctx.g = w, b, g
+        if act_tok is None:
+            check(lib.gan_conv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
+            ctx.save_for_backward(x)
+        else:
+            code, param, scale, shift = act_tok.spec
+            check(lib.gan_conv2d_fwd_act(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), code, param, scale, shift,
+                                         wp, wn, stream()))
+            ctx.save_for_backward(x, y)
+        ctx.w, ctx.b, ctx.g, ctx.act_tok, ctx.in_tok = w, b, g, act_tok, in_tok
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         w, b, g = ctx.w, ctx.b, ctx.g
         dy = _dense(dy)
+        if ctx.act_tok is not None:
+            dy = _through_own_activation(ctx, ctx.saved_tensors[1], dy)
         wp, wn = _conv_ws(g)
         if w.wants_grad:
             dw, acc = w.grad_target()
@@ -151,26 +195,40 @@ class _Conv2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.gan_conv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
-        return dx, None, None, None, None
+            if ctx.in_tok is None:
+                check(lib.gan_conv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
+            else:       # x is the activated output of the layer below: hand it the gradient in front of its activation
+                code, param, scale, shift = ctx.in_tok.spec
+                check(lib.gan_conv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param, scale,
+                                                 shift, wp, wn, stream()))
+                ctx.in_tok.grad_ptr = dx.data_ptr()
+        return dx, None, None, None, None, None, None
 
 
 class _Deconv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, token, w, b, g):
+    def forward(ctx, x, token, w, b, g, act_tok, in_tok):
         x = _dense(x)
         y = torch.empty((g.n, g.hb, g.wb, g.cb), dtype=torch.float32, device=x.device)
         wp, wn = _conv_ws(g)
-        check(lib.gan_deconv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
-        ctx.save_for_backward(x)
-        ctx.w, ctx.b, ctx.g = w, b, g
+        if act_tok is None:
+            check(lib.gan_deconv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
+            ctx.save_for_backward(x)
+        else:
+            code, param, scale, shift = act_tok.spec
+            check(lib.gan_deconv2d_fwd_act(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), code, param, scale,
+                                           shift, wp, wn, stream()))
+            ctx.save_for_backward(x, y)
+        ctx.w, ctx.b, ctx.g, ctx.act_tok, ctx.in_tok = w, b, g, act_tok, in_tok
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         w, b, g = ctx.w, ctx.b, ctx.g
         dy = _dense(dy)
+        if ctx.act_tok is not None:
+            dy = _through_own_activation(ctx, ctx.saved_tensors[1], dy)
         wp, wn = _conv_ws(g)
         if w.wants_grad:
             dw, acc = w.grad_target()
@@ -180,8 +238,14 @@ class _Deconv2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.gan_deconv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
-        return dx, None, None, None, None
+            if ctx.in_tok is None:
+                check(lib.gan_deconv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
+            else:
+                code, param, scale, shift = ctx.in_tok.spec
+                check(lib.gan_deconv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param,
+                                                   scale, shift, wp, wn, stream()))
+                ctx.in_tok.grad_ptr = dx.data_ptr()
+        return dx, None, None, None, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -217,8 +281,19 @@ class _LinearFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding='SAME', name="conv2d"):
-    """ops.py:64-74: w [k_h,k_w,Cin,Cout] truncated-normal, biases zeros, tf.nn.conv2d + bias_add."""
+def _fused_act_of(t):
+    """The token of a conv / deconv output with a fused activation (None for any other tensor)."""
+    return getattr(t, '_gan_act', None) if torch.is_grad_enabled() and t.requires_grad else None
+
+
+def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding='SAME', name="conv2d", *,
+           act=None, act_param=0.2, act_scale=1.0, act_shift=0.0):
+    """ops.py:64-74: w [k_h,k_w,Cin,Cout] truncated-normal, biases zeros, tf.nn.conv2d + bias_add.
+
+    Extension (keyword-only; the default is the reference's op): `act` fuses the activation the caller would
+    apply to the result -- lrelu(conv2d(..)) of dcgan.py:328 is conv2d(.., act='lrelu') -- into the store, as
+    act(conv + bias) * act_scale + act_shift.  Such an output must feed ONE consumer; when that consumer is a
+    conv2d / deconv2d, its input-gradient pass also applies this activation's derivative."""
     st = V.default_store()
     n, h, w_, cin = input_.shape
     with st.variable_scope(name):
@@ -227,12 +302,19 @@ def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding=
     g = _conv_geom(n, h, w_, cin, output_dim, k_h, k_w, d_h, d_w, padding)
     if autotune.enabled():
         autotune.tune_geometry(g)
-    return _Conv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g)
+    spec = _act_spec(act, act_param, act_scale, act_shift)
+    tok = _ActToken(spec) if spec is not None else None
+    y = _Conv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_))
+    if tok is not None:
+        y._gan_act = tok
+    return y
 
 
-def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="deconv2d", with_w=False):
+def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="deconv2d", with_w=False, *,
+             act=None, act_param=0.2, act_scale=1.0, act_shift=0.0):
     """ops.py:76-99: w [k_h,k_w,Cout,Cin] normal, tf.nn.conv2d_transpose (SAME) + bias_add.
-    `output_shape` carries the static batch size, as in the reference."""
+    `output_shape` carries the static batch size, as in the reference.  `act` ...: as for conv2d (the returned
+    tensor is then the ACTIVATED one: tanh(deconv2d(..)) of dcgan.py:385 is deconv2d(.., act='tanh'))."""
     st = V.default_store()
     n, hs, ws, cin = input_.shape
     on, oh, ow, oc = [int(v) for v in output_shape]
@@ -244,7 +326,11 @@ def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name
     g = _conv_geom(n, oh, ow, oc, cin, k_h, k_w, d_h, d_w, 'SAME', small_hw=(hs, ws))
     if autotune.enabled():
         autotune.tune_geometry(g)
-    deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g)
+    spec = _act_spec(act, act_param, act_scale, act_shift)
+    tok = _ActToken(spec) if spec is not None else None
+    deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_))
+    if tok is not None:
+        deconv._gan_act = tok
     if with_w:
         return deconv, w, biases
     return deconv

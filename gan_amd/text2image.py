@@ -120,9 +120,8 @@ class Text2Image(object):
             h3 = ops.deconv2d(h2, [bs, s2, s2, self.gf_dim * 1], name='g_h3')
             h3 = self.g_bn3(h3, train=train, act='relu')
 
-            h4 = ops.deconv2d(h3, [bs, s, s, 3], name='g_h4')
-
-            return ops.tanh(h4, scale=0.5, shift=0.5)      # tf.tanh(h4)/2. + 0.5
+            # tf.tanh(h4)/2. + 0.5, applied in the deconv's epilogue
+            return ops.deconv2d(h3, [bs, s, s, 3], name='g_h4', act='tanh', act_scale=0.5, act_shift=0.5)
 
     # DISCRIMINATOR (text2image.py:201-222)
     def discriminator(self, image, t_text_embedding, reuse=False, passes=1, with_prob=True):
@@ -134,7 +133,7 @@ class Text2Image(object):
             if reuse:
                 scope.reuse_variables()
 
-            h0 = ops.lrelu(ops.conv2d(image, self.df_dim, name='d_h0_conv'))                                       # 32
+            h0 = ops.conv2d(image, self.df_dim, name='d_h0_conv', act='lrelu')                                       # 32
             h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)         # 16
             h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)         # 8
             if isinstance(self._d_bound, list):

@@ -92,6 +92,28 @@ int gan_deconv2d_dgrad(const gan_conv_geom* g, const float* dy, const float* w, 
 int gan_deconv2d_wgrad(const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
                        int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream);
 
+/* ---- conv / deconv with the activation that follows it fused into the store ------------------
+ * The reference applies an activation directly to a conv output in its layers without batch norm:
+ * lrelu(conv2d(image)) (dcgan.py:328, cyclegan_module.py:20), tanh(deconv2d(h3)) (dcgan.py:385),
+ * sigmoid(deconv2d(h2)) (dcgan.py:409), tanh(h4)/2. + 0.5 (text2image.py:198), tanh(conv2d) (cyclegan_module.py:145).
+ *   *_fwd_act:      y = act(conv + bias) * act_scale + act_shift, in the contraction's epilogue.
+ *   *_dgrad_gated:  the input gradient of the NEXT layer, multiplied on store by the activation derivative
+ *                   of this layer: dx = dgrad(dy, w) * d(act(.)*scale+shift)/d(.) evaluated from the saved
+ *                   activated tensor `gate` (shaped like dx).  What comes out is the gradient with respect to
+ *                   the conv output in front of the activation, so no activation-backward pass runs. */
+int gan_conv2d_fwd_act(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                       int act, float act_param, float act_scale, float act_shift, void* ws, size_t ws_bytes,
+                       gan_stream_t stream);
+int gan_deconv2d_fwd_act(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                         int act, float act_param, float act_scale, float act_shift, void* ws, size_t ws_bytes,
+                         gan_stream_t stream);
+int gan_conv2d_dgrad_gated(const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                           const float* gate, int act, float act_param, float act_scale, float act_shift,
+                           void* ws, size_t ws_bytes, gan_stream_t stream);
+int gan_deconv2d_dgrad_gated(const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                             const float* gate, int act, float act_param, float act_scale, float act_shift,
+                             void* ws, size_t ws_bytes, gan_stream_t stream);
+
 /* ---- tf.matmul(input_, matrix) + bias (ops.py:113-115) and its gradients ----------- */
 size_t gan_linear_workspace_bytes(int rows, int in_dim, int out_dim);
 int gan_linear_fwd(int rows, int in_dim, int out_dim, const float* x, const float* matrix,

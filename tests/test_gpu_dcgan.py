@@ -84,11 +84,11 @@ def test_update_gradients_match_oracle(cond):
     for v in gpu.d_group.variables:
         if is_noise_grad(v.name, d_ref):
             continue        # Adam normalises pure rounding noise to a +-lr step: not comparable
-        assert_close(v.data.cpu().numpy(), ref.st.values[v.name], "post-Adam " + v.name, tol=1e-4)
+        assert_close(v.data.cpu().numpy(), ref.st.values[v.name], "post-Adam " + v.name, tol=1e-4, elementwise=False)
     for n, v in gpu.store.vars.items():
         if 'moving_' in n:
             # a moving mean near zero is compared on the scale of the matching standard deviation
-            assert_close(v.data.cpu().numpy(), ref.st.values[n], n, tol=1e-3)
+            assert_close(v.data.cpu().numpy(), ref.st.values[n], n, tol=1e-3, elementwise=False)
     assert gpu.d_optim.steps_taken == 1 and gpu.g_optim.steps_taken == 0
     # G update from the now-identical state
     gpu.store.load_state_dict(ref.st.values)
@@ -153,10 +153,10 @@ def test_logging_evals_and_sampler():
     for n, v in gpu.store.vars.items():
         if 'moving_' in n:
             # a moving mean near zero is compared on the scale of the matching standard deviation
-            assert_close(v.data.cpu().numpy(), ref.st.values[n], n, tol=5e-3)   # three Adam steps in
+            assert_close(v.data.cpu().numpy(), ref.st.values[n], n, tol=5e-3, elementwise=False)   # three Adam steps in
     s_ref = ref.sample(z)
     s = gpu.sampler(torch.from_numpy(z).cuda())
-    assert_close(s.cpu().numpy(), s_ref, "sampler output", tol=5e-4)
+    assert_close(s.cpu().numpy(), s_ref, "sampler output", tol=5e-4, elementwise=False)
 
 
 def test_hip_graph_replay_equals_eager():

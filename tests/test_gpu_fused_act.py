@@ -1,0 +1,132 @@
+"""conv / deconv with the following activation fused into the store, and the gated input-gradient entry points
+that hand a layer the gradient in front of its activation: against the float64 oracle through the C ABI, and the
+Python-level protocol (ops.conv2d(act=...) -> consumer conv) against the unfused composition."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+ACTS = [(1, 0.0, 1.0, 0.0), (2, 0.2, 1.0, 0.0), (3, 0.0, 1.0, 0.0), (3, 0.0, 0.5, 0.5), (4, 0.0, 1.0, 0.0)]
+
+
+def _act(z, act, param):
+    if act == 1:
+        return np.maximum(z, 0)
+    if act == 2:
+        return np.maximum(z, param * z)
+    if act == 3:
+        return np.tanh(z)
+    return 1 / (1 + np.exp(-z))
+
+
+def _dact(z, act, param):
+    if act == 1:
+        return (z > 0).astype(np.float64)
+    if act == 2:
+        return np.where(z >= 0, 1.0, param)
+    if act == 3:
+        return 1 - np.tanh(z) ** 2
+    s = 1 / (1 + np.exp(-z))
+    return s * (1 - s)
+
+
+# n, h, w, cb, cs, k, s: a split-K case on the bf16 path, a direct-epilogue case, a thin (3-channel) big side, odd channels
+CASES = [(8, 16, 16, 64, 128, 5, 2), (2, 9, 13, 8, 12, 5, 2), (2, 12, 12, 3, 16, 5, 2), (3, 14, 14, 21, 10, 3, 1)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("act,param,scale,shift", ACTS)
+def test_fused_activation_entry_points(case, act, param, scale, shift):
+    from gan_amd import _lib as L
+    from gpu_util import assert_close, dev, geom_for, host
+    n, h, w_, cb, cs, k, s = case
+    g = geom_for(n, h, w_, cb, cs, k, s, 'SAME')
+    gp = ctypes.byref(g)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w_, cb)).astype(np.float32)
+    xs = rng.standard_normal((n, g.hs, g.ws, cs)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cb, cs)) * 0.1).astype(np.float32)
+    bc, bd = rng.standard_normal(cs).astype(np.float32), rng.standard_normal(cb).astype(np.float32)
+    wp, wn = L.workspace(int(L.lib.gan_conv_workspace_bytes(gp)))
+    st = L.stream()
+    d = np.float64
+    x_d, xs_d, wt_d, bc_d, bd_d = dev(x), dev(xs), dev(wt), dev(bc), dev(bd)     # kept alive across the launches
+    # conv2d forward + activation
+    y = torch.empty(n, g.hs, g.ws, cs, device='cuda')
+    L.check(L.lib.gan_conv2d_fwd_act(gp, L.ptr(x_d), L.ptr(wt_d), L.ptr(bc_d), L.ptr(y), act, param, scale, shift, wp, wn, st))
+    z = T.conv2d_forward(x.astype(d), wt.astype(d), s, s, 'SAME') + bc
+    # tanh / sigmoid compress a sum of magnitude ~10 into [-1, 1]: the rounding of the sum, not of the output, sets
+    # the absolute error, so the elementwise bound (relative to the output's own scale) applies to relu / lrelu only
+    ew = act in (1, 2)
+    assert_close(host(y), _act(z, act, param) * scale + shift, "conv2d_fwd_act", elementwise=ew)
+    # conv2d_transpose forward + activation
+    yt = torch.empty(n, h, w_, cb, device='cuda')
+    L.check(L.lib.gan_deconv2d_fwd_act(gp, L.ptr(xs_d), L.ptr(wt_d), L.ptr(bd_d), L.ptr(yt), act, param, scale, shift, wp, wn, st))
+    zt = T.conv2d_transpose_forward(xs.astype(d), wt.astype(d), (n, h, w_, cb), s, s) + bd
+    assert_close(host(yt), _act(zt, act, param) * scale + shift, "deconv2d_fwd_act", elementwise=ew)
+    # gated input gradients: the gate is the activated tensor of the layer below (pre-activations kept clear of the kinks)
+    zg_big = rng.standard_normal((n, h, w_, cb))
+    zg_big[np.abs(zg_big) < 1e-3] = 0.5
+    gate_big = (_act(zg_big, act, param) * scale + shift).astype(np.float32)
+    dx = torch.empty(n, h, w_, cb, device='cuda')
+    gb_d = dev(gate_big)
+    L.check(L.lib.gan_conv2d_dgrad_gated(gp, L.ptr(xs_d), L.ptr(wt_d), L.ptr(dx), L.ptr(gb_d), act, param, scale, shift,
+                                         wp, wn, st))
+    want = T.conv2d_backward_input(xs.astype(d), wt.astype(d), x.shape, s, s, 'SAME') * _dact(zg_big, act, param) * scale
+    # the derivative is rebuilt from the float32 gate: tanh / sigmoid lose relative accuracy where they saturate
+    assert_close(host(dx), want, "conv2d_dgrad_gated", tol=1e-4 if act in (1, 2) else 5e-4, elementwise=act in (1, 2))
+    zg_small = rng.standard_normal((n, g.hs, g.ws, cs))
+    zg_small[np.abs(zg_small) < 1e-3] = 0.5
+    gate_small = (_act(zg_small, act, param) * scale + shift).astype(np.float32)
+    dxs = torch.empty(n, g.hs, g.ws, cs, device='cuda')
+    gs_d = dev(gate_small)
+    L.check(L.lib.gan_deconv2d_dgrad_gated(gp, L.ptr(x_d), L.ptr(wt_d), L.ptr(dxs), L.ptr(gs_d), act, param, scale,
+                                           shift, wp, wn, st))
+    want = T.conv2d_forward(x.astype(d), wt.astype(d), s, s, 'SAME') * _dact(zg_small, act, param) * scale
+    assert_close(host(dxs), want, "deconv2d_dgrad_gated", tol=1e-4 if act in (1, 2) else 5e-4, elementwise=act in (1, 2))
+
+
+@pytest.mark.parametrize("consumer", ["conv", "deconv", "other"])
+def test_fused_activation_protocol_equals_the_unfused_composition(consumer):
+    """ops.conv2d(act='lrelu') followed by a conv / deconv (gated input gradient) or by another op (fallback:
+    activation-backward kernel) gives the gradients of lrelu(conv2d(..)) composed from separate ops."""
+    from gan_amd import ops, variables as V
+    from gan_amd.optim import AdamOptimizer
+    torch.manual_seed(3)
+    x = torch.randn(4, 16, 16, 8, device='cuda')
+    results = []
+    for fused in (True, False):
+        store = V.VariableStore(device='cuda', seed=11)
+        with V.use_store(store):
+            def net(inp):
+                with ops.variable_scope("n"):
+                    if fused:
+                        h = ops.conv2d(inp, 16, name='c0', act='lrelu')
+                    else:
+                        h = ops.lrelu(ops.conv2d(inp, 16, name='c0'))
+                    if consumer == "conv":
+                        o = ops.conv2d(h, 8, 3, 3, 1, 1, name='c1')
+                    elif consumer == "deconv":
+                        o = ops.deconv2d(h, [4, 16, 16, 8], name='c1')
+                    else:
+                        o = ops.linear(h.reshape(4, -1), 5, 'c1')
+                    return ops.mse_const_mean(o, 0.3)
+            loss = net(x)
+            group = store.pack('n', store.trainable_variables())
+            opt = AdamOptimizer(1e-3, beta1=0.5).attach(group)
+            opt.begin()
+            xin = x.clone().requires_grad_(True)
+            loss = net(xin)
+            ops.backward(loss)
+            opt.finish_grads()
+            torch.cuda.synchronize()
+            results.append((float(loss.detach()), group.grads.clone(), xin.grad.clone()))
+    (l0, g0, dx0), (l1, g1, dx1) = results
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l1))
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx1.abs().max())

@@ -313,7 +313,7 @@ def test_batch_norm_stacked_passes_equal_separate_calls():
         res.append((host(y), dx, host(st.vars['bn/gamma'].grad), host(st.vars['bn/beta'].grad),
                     host(st.vars['bn/moving_mean'].data), host(st.vars['bn/moving_variance'].data)))
     for got, want, what in zip(res[1], res[0], ("y", "dx", "dgamma", "dbeta", "moving_mean", "moving_variance")):
-        assert_close(got, want, "stacked batch_norm " + what, tol=1e-6)
+        assert_close(got, want, "stacked batch_norm " + what, tol=1e-6, elementwise=False)
 
 
 def test_cyclegan_shared_generator_passes_equal_run_by_run():
