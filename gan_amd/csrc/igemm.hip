@@ -640,10 +640,18 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
     __shared__ __attribute__((aligned(16))) float tile[(kThinQH + MAXT - 1) * (kThinQW + MAXT - 1) * kThinPix];
     const gan_conv_geom& g = p.g;
     const int ci = blockIdx.y;
-    ClassInfo cl = p.cls[0];
-    if (ci == 1) cl = p.cls[1];
-    else if (ci == 2) cl = p.cls[2];
-    else if (ci == 3) cl = p.cls[3];
+    // This block's class and, at the very end, the epilogue come straight from the kernel-argument segment (the one
+    // by-value argument starts at its offset 0) by scalar loads where they are needed, instead of being held in
+    // scalar registers from the kernel's entry on: the tap loop runs at the scalar-register limit.
+    ClassInfo cl;
+    Epilogue epi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ThinArgs* ka = (const ThinArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    __builtin_memcpy(&cl, &ka->cls[ci], sizeof(cl));
+#else
+    cl = p.cls[0];
+    epi = p.epi;
+#endif
     int b = blockIdx.x;
     const int tw = b % p.tiles_w; b /= p.tiles_w;
     const int th = b % p.tiles_h;
@@ -697,11 +705,14 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
     if (qh < cl.hq && qw < cl.wq) {
         const int h = (cl.hq0 + qh) * g.sh + cl.ph - g.pt, w = (cl.wq0 + qw) * g.sw + cl.pw - g.pl;
         float* o = p.out + (((long)img * g.hb + h) * g.wb + w) * g.cb;
-        const bool epi_on = epi_active(p.epi);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_memcpy(&epi, &ka->epi, sizeof(epi));
+#endif
+        const bool epi_on = epi_active(epi);
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             float v = acc[c] + (p.bias ? p.bias[c] : 0.f);
-            if (epi_on) v = epi_apply(p.epi, v, (o - p.out) + c);
+            if (epi_on) v = epi_apply(epi, v, (o - p.out) + c);
             o[c] = v;
         }
     }

@@ -78,5 +78,26 @@ def main():
              weight_seed=WEIGHT_SEED, data_seed=DATA_SEED, batch=BATCH)
 
 
+def add_float32_yardstick(n):
+    """Adds `losses_f32`: the first n iterations of the same trajectory from the oracle run in float32 (numpy),
+    i.e. how far float32 rounding alone moves this trajectory away from the float64 one.
+        python tests/golden/make_dcgan64_traj.py f32 40"""
+    path = os.path.join(HERE, "dcgan64_traj200.npz")
+    gold = dict(np.load(path))
+    st, net = initial_oracle(np.float32)
+    rng = np.random.default_rng(DATA_SEED)
+    out = np.zeros((n, 3))
+    for it in range(n):
+        im, z = draw(rng)
+        o = net.train_iteration(im, z)
+        out[it] = (o['d_loss'], o['g_loss_1'], o['g_loss_2'])
+        print("float32 iteration %d  deviation from float64 %.3e" % (it, np.abs(out[it] - gold['losses'][it]).max()), flush=True)
+    gold['losses_f32'] = out
+    np.savez(path, **gold)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "f32":
+        add_float32_yardstick(int(sys.argv[2]))
+    else:
+        main()
