@@ -5,7 +5,8 @@ beta1 0.5; one D update + two G updates per iteration, models/dcgan.py:226-279 o
 Only the 200 x 3 losses and the seeds are stored: the initial weights come from the oracle's seeded
 initialisers (rounded to float32, so that the GPU side starts from the very same numbers) and every
 iteration's images and z are drawn from one seeded generator, exactly as the test that replays the
-trajectory draws them.  The reference ships no fixture and TensorFlow 1.x cannot run here: like the
+trajectory draws them.  `losses_f32` (second mode, below) holds the first 60 iterations from the oracle run in
+float32: the yardstick for what rounding alone does to this trajectory.  The reference ships no fixture and TensorFlow 1.x cannot run here: like the
 other files of this directory this pins the ORACLE.  About half an hour on 8 cores:
     python tests/golden/make_dcgan64_traj.py [iterations]
 """

@@ -225,11 +225,14 @@ def test_dcgan64_full_size_loss_trajectory_200_steps():
     against the committed float64-oracle trajectory tests/golden/dcgan64_traj200.npz (generator script
     alongside: same weight seed, same data generator, so only losses and seeds are stored).
 
-    Stated tolerance: |loss - float64 oracle| <= 2e-2 over the first 20 iterations and <= 1e-1 over all 200,
-    for each of d_loss, g_loss (first update), g_loss (second update).  Training amplifies rounding (Adam
-    turns near-zero gradients into +-lr steps, relu / leaky-relu units at their kink flip), which is why the
-    bar widens with the iteration count; the float32 numpy oracle's own drift is of the same size
-    (test_gpu_dcgan.test_schedule_and_loss_trajectory_200_steps measures both side by side at a small size)."""
+    At this size, on noise images, training is chaotic in the numerical sense: Adam turns the rounding noise of
+    10^7 near-zero gradients into +-lr steps and relu / leaky-relu units flip at their kink, so ANY float32
+    evaluation leaves the float64 trajectory quickly -- the oracle itself, run in float32 numpy, is 0.06 off
+    after 5 iterations, 0.6 after 12 and 1.7 after 28 (`losses_f32` in the fixture, the yardstick).  Stated
+    tolerance: (a) over the 60 iterations the yardstick covers, the running maximum of |loss - float64 oracle|
+    stays within 4x the yardstick's running maximum (+ 2e-3); (b) the first iteration agrees to 1e-3 of the loss; (c) over
+    all 200 iterations every loss is finite and the mean of each loss over the last 100 iterations agrees with
+    the float64 oracle's to 25 %: the two runs have decorrelated by then but sample the same dynamics."""
     import os
     import sys
     from gan_amd.dcgan import DCGAN
@@ -242,7 +245,7 @@ def test_dcgan64_full_size_loss_trajectory_200_steps():
         sys.path.remove(here)
     gold = np.load(os.path.join(here, "dcgan64_traj200.npz"))
     assert int(gold['weight_seed']) == M.WEIGHT_SEED and int(gold['data_seed']) == M.DATA_SEED and int(gold['batch']) == 64
-    want = gold['losses']
+    want, yard = gold['losses'], gold['losses_f32']
     st, _ = M.initial_oracle()
     opts = argparse.Namespace(model='DCGAN', dataset='celebA', batch_size=64, input_height=108, input_width=108,
                               output_height=64, output_width=64, y_dim=None, z_dim=100, gf_dim=64, df_dim=64,
@@ -260,12 +263,18 @@ def test_dcgan64_full_size_loss_trajectory_200_steps():
     got = np.array([[float(o['d_loss_real']) + float(o['d_loss_fake']), float(o['g_loss_1']), float(o['g_loss_2'])]
                     for o in outs])
     assert np.isfinite(got).all()
-    dev_ = np.abs(got - want).max(axis=1)
-    print("max |loss - float64 oracle| over 20 / 200 iterations at DCGAN-64, batch 64: %.3e / %.3e"
-          % (dev_[:20].max(), dev_.max()))
     assert gpu.d_optim.steps_taken == 200 and gpu.g_optim.steps_taken == 400
-    assert dev_[:20].max() <= 2e-2
-    assert dev_.max() <= 1e-1
+    n = yard.shape[0]
+    dev_gpu = np.maximum.accumulate(np.abs(got[:n] - want[:n]).max(axis=1))
+    dev_f32 = np.maximum.accumulate(np.abs(yard - want[:n]).max(axis=1))
+    tail_gpu, tail_ref = got[100:].mean(axis=0), want[100:].mean(axis=0)
+    print("running max |loss - float64 oracle| at iterations 1 / 5 / 10 / 20 / 60: gpu %s, float32 numpy oracle %s; "
+          "mean losses over iterations 100-199: gpu %s, float64 oracle %s"
+          % (np.round(dev_gpu[[0, 4, 9, 19, n - 1]], 4), np.round(dev_f32[[0, 4, 9, 19, n - 1]], 4),
+             np.round(tail_gpu, 3), np.round(tail_ref, 3)))
+    assert dev_gpu[0] <= 1e-3 * max(1.0, float(np.abs(want[0]).max()))      # losses of magnitude ~10 here
+    assert (dev_gpu <= 4 * dev_f32 + 2e-3).all(), np.nonzero(dev_gpu > 4 * dev_f32 + 2e-3)[0][:5]
+    assert (np.abs(tail_gpu - tail_ref) <= 0.25 * np.abs(tail_ref)).all()
 
 
 def _finite_grads(optims):
