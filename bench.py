@@ -410,7 +410,7 @@ def main():
                                                                else "hipGraph segments + %s all-reduce overlapped with the backward pass"
                                                                % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")),
                        "schedule": "the first G update reuses the D update's generator pass (same z, same weights; "
-                                   "results identical to re-running it)",
+                                   "trained weights identical to re-running it, batch-norm moving variances equal to float32 rounding)",
                        "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},
             "roofline": roof,
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / peak, 4),

@@ -726,15 +726,17 @@ struct TileCfg {
 };
 
 struct Plan {
-    int cfg;  // fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32; split-bf16 MFMA 4: 128x128, 5: 128x64, 6: 64x64
+    int cfg;  // fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32; split-bf16 MFMA 4: 128x128, 5: 128x64, 6: 64x64,
+              // 7: 128x128 and 8: 128x64 with split-K inside the workgroup (two groups of four waves per tile)
     int va, vb;
     int splits, kt_per_split;
     int mt, nt;
     long out_elems;
 };
 
-static const TileCfg kCfg[7] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}};
-constexpr int kFirstSplitCfg = 4, kNumCfg = 7;
+static const TileCfg kCfg[9] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64},
+                                {128, 128}, {128, 64}};
+constexpr int kFirstSplitCfg = 4, kFirstKg2Cfg = 7, kNumCfg = 9;
 
 // Process-wide switch: 1 keeps every contraction on the fp32 MFMA (bitwise an fmaf chain); 0 lets
 // layers whose channel counts are multiples of 4 run on the bf16 matrix pipe with fp32 operands
@@ -874,7 +876,8 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     }
     if (knobs().force_cfg >= 0) pl.cfg = knobs().force_cfg % kNumCfg;
     // a pinned or forced split configuration on operands that cannot take it (unaligned views, exact mode)
-    if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;
+    if (pl.cfg >= kFirstKg2Cfg && !split_ok) pl.cfg -= kFirstKg2Cfg;
+    else if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;
     const int bm = kCfg[pl.cfg].bm, bn = kCfg[pl.cfg].bn;
     pl.mt = (M + bm - 1) / bm;
     pl.nt = (N + bn - 1) / bn;
@@ -883,10 +886,13 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     int splits = 1;
     // one co-resident wave of blocks: the fp32 kernel fits 3 blocks per CU, the split kernel 2
     // (LDS and registers allow 2 / 3 / 5 blocks per CU for its 128x128 / 128x64 / 64x64 tiles)
-    const long target = pl.cfg == 4 ? 512 : (pl.cfg == 5 ? 768 : (pl.cfg == 6 ? 1280 : 768));
+    // (the two-group tiles hold 8 waves each: one 128x128 or two 128x64 workgroups per CU)
+    const long target = pl.cfg == 4 ? 512 : (pl.cfg == 5 ? 768 : (pl.cfg == 6 ? 1280 : (pl.cfg == 7 ? 256 : (pl.cfg == 8 ? 512 : 768))));
     if (blocks < target) {
         splits = (int)(target / blocks);
-        const int max_by_k = nkt / 12 > 0 ? nkt / 12 : 1;  // keep >= 12 k-slices per split: shorter loops are all prologue
+        // keep >= 12 k-slices per wave group: shorter loops are all prologue
+        const int kdiv = pl.cfg >= kFirstKg2Cfg ? 24 : 12;
+        const int max_by_k = nkt / kdiv > 0 ? nkt / kdiv : 1;
         if (splits > max_by_k) splits = max_by_k;
         // the slabs are written once and read once: keep them to a few tens of MB
         const long max_by_bytes = (48L << 20) / (pl.out_elems * (long)sizeof(float) + 1);
@@ -961,15 +967,15 @@ static void launch_vec(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
 
 // The split kernel's cheap gather arithmetic needs 16-channel alignment of the gathered image (FPROP: big
 // side, TPROP: small side) or, for WGRAD, a small-image width that is a multiple of 4.
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int KG = 1>
 static void launch_split(const IgemmArgs& a, dim3 grid, hipStream_t s) {
     const gan_conv_geom& g = a.g;
     const bool fast = (MODE == MODE_FPROP) ? (g.cb % 16 == 0)
                     : (MODE == MODE_TPROP) ? (g.cs % 16 == 0) : (g.ws % 4 == 0);
     if (fast && !knobs().slow_gather)
-        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, true, KG>), grid, dim3(256 * KG), 0, s, a);
     else
-        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false, KG>), grid, dim3(256 * KG), 0, s, a);
 }
 
 template <int MODE>
@@ -981,7 +987,9 @@ static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         case 3: launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break;
         case 4: launch_split<MODE, 128, 128>(a, grid, s); break;
         case 5: launch_split<MODE, 128, 64>(a, grid, s); break;
-        default: launch_split<MODE, 64, 64>(a, grid, s); break;
+        case 6: launch_split<MODE, 64, 64>(a, grid, s); break;
+        case 7: launch_split<MODE, 128, 128, 2>(a, grid, s); break;
+        default: launch_split<MODE, 128, 64, 2>(a, grid, s); break;
     }
 }
 

@@ -57,8 +57,13 @@ __device__ __forceinline__ int unpermute(int pos) {
 //     unit, and a thread's offset is a constant of the thread plus a per-slice scalar;
 //   WGRAD: the small image's width is a multiple of 4, so the 4 consecutive pixels a thread gathers
 //     share an image row: one pixel decode per slice instead of four.
-template <int MODE, int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
+//
+// KG = 2: split-K inside the workgroup.  The workgroup has two groups of four waves; both work on the SAME
+// output tile, group g on the g-th half of the workgroup's k range with staging buffers of its own, and the
+// second group hands its accumulators to the first through LDS at the end.  A launch then needs half as many
+// split-K slabs (written once, read once by the reduction) for the same number of waves on the chip.
+template <int MODE, int BM, int BN, int WM, int WN, bool FAST, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p) {
     static_assert(WM * WN == 4, "four waves per block");
     static_assert(BM % 64 == 0 && BN % 64 == 0, "tile sides are multiples of 64");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -69,9 +74,13 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     constexpr int STAGE = 3 * (PA + PB);
     // vector instructions of one slice (split, address arithmetic) per MFMA of that slice
     constexpr int kValuPerMfma = (TM * TN >= 4) ? (FAST ? 5 : 7) : (TM * TN == 2 ? (FAST ? 8 : 11) : (FAST ? 14 : 20));
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[2 * STAGE];
+    static_assert(KG == 1 || KG == 2, "one or two k groups");
+    static_assert(KG == 1 || TM * TN * 16 * 256 * 4 <= KG * 2 * STAGE, "the accumulator hand-over must fit the staging buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[KG * 2 * STAGE];
 
-    const int tid = threadIdx.x;
+    const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    unsigned char* const smem_raw = smem_all + kgrp * (2 * STAGE);
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -93,9 +102,14 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
     if (m0 >= M) return;  // block-uniform
     const int n0 = blockIdx.y * BN;
     const int nkt = (K + BK - 1) / BK;
-    const int kt0 = split * p.kt_per_split;
-    const int kt1 = min(nkt, kt0 + p.kt_per_split);
-    const int kend = min(K, kt1 * BK);
+    // the workgroup's k range, divided over its k groups; every group runs `per_group` slices (a group whose
+    // share is shorter multiplies zeros at the end: the barriers must match)
+    const int bk0 = split * p.kt_per_split;
+    const int bk1 = min(nkt, bk0 + p.kt_per_split);
+    const int per_group = (max(bk1 - bk0, 0) + KG - 1) / KG;
+    const int kt0 = bk0 + kgrp * per_group;
+    const int kt1 = min(bk1, kt0 + per_group);
+    const int kend = min(K, max(kt1, kt0) * BK);
 
     // ---------------------------------------------------------------- A loader set-up
     constexpr int A_PASS = A_TRANS ? BM / 64 : 4;   // k-contiguous: rows per thread; else: k rows per thread
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (kt0 < kt1) {
+    if (per_group > 0) {
         // Software pipeline with two register sets and two LDS buffers, one barrier per slice
         // (slices past the end load zeros and are never multiplied).
         AReg a0, a1;
@@ -412,15 +426,38 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(const IgemmArgs p) {
         __syncthreads();
         // two slices per trip keep the register sets and LDS buffers compile-time; an odd slice count
         // multiplies one slice of zeros at the end
-        for (int kt = kt0; kt < kt1; kt += 2) {
+        for (int kt = kt0; kt < kt0 + per_group; kt += 2) {
             slice(0, a1, b1, kt + 3);
             slice(1, a0, b0, kt + 4);
         }
     }
+    if constexpr (KG > 1) {
+        // the second group's accumulators -> LDS (register-major: conflict free), first group adds them and goes on
+        // alone; a wave that has ended no longer counts at the barriers of the epilogue
+        float* red = reinterpret_cast<float*>(smem_all);
+        if (kgrp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 256 + tid];
+    }
 
     // ---------------------------------------------------------------- epilogue (as igemm_kernel, plus the
     // row / column permutation of operands filled by the row-pair loader)
-    float* smem = reinterpret_cast<float*>(smem_raw);
+    // (staging reuses the buffers, the hand-over area included: the barrier behind the row table below comes after
+    // every read of it)
+    float* smem = reinterpret_cast<float*>(smem_all);
     __shared__ int rowoff[BM];
     if (tid < BM) {
         const int m = m0 + tid;

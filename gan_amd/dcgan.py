@@ -254,7 +254,9 @@ class DCGAN(object):
         (dcgan.py:228-247) with the same z and the same generator weights: the second evaluation
         repeats the first bit for bit.  reuse_g=True takes the pass d_grads(keep_g=True) recorded
         instead of recomputing it, and applies the batch-norm moving-average updates that second
-        evaluation would have made."""
+        evaluation would have made (gan_bn_moving_update rebuilds the batch variance from the saved 1/sqrt(var+eps),
+        so the moving variance matches a second evaluation to float32 rounding, not bit for bit; the trained
+        weights never read it)."""
         with V.use_store(self.store):
             self.g_optim.begin()
             kept, self._g_pass = getattr(self, '_g_pass', None), None
@@ -363,7 +365,15 @@ class DCGAN(object):
         (opts.dataset_cache_gb, default 32: CelebA at 64x64 is 2.4 GB), so that later epochs decode nothing.
 
         Data parallel (world_size N): the ranks take consecutive batches of that sequence (N x batch_size
-        items per step, each rank its own z), rank 0 prints, samples and saves."""
+        items per step, each rank its own z), rank 0 prints, samples and saves.
+
+        Deliberate deviation: the reference re-evaluates errD_fake / errD_real / errG after EVERY iteration
+        (dcgan.py:249-260, 277-279), and each of those training-mode passes also moves the batch-norm moving
+        averages.  Here they run on logged iterations only: with opts.print_every == 1 (the default) that is
+        every iteration, as in the reference; a larger print_every (an extension) skips the evaluations and
+        their moving-average updates in between, which changes sampler output and checkpointed statistics,
+        never the trained weights.  Likewise the sample step runs the sampler only, not the reference's extra
+        d_loss / g_loss evaluation (:289-296)."""
         from glob import glob
         from .misc import save_images
         from .prefetch import BatchPrefetcher, to_device

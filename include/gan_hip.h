@@ -214,7 +214,8 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
  *   mode 2: conv2d_wgrad, deconv2d_wgrad, linear_wgrad
  * gan_conv_plan_set pins the tile configuration (fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64,
  * 3: 128x32; bf16 MFMA on fp32 operands split into three bf16 parts 4: 128x128, 5: 128x64,
- * 6: 64x64, which need channel counts that are multiples of 4 and fall back to 0..2 otherwise) and
+ * 6: 64x64, 7: 128x128 and 8: 128x64 with the split-K halved inside the workgroup -- two groups of four waves
+ * share one output tile --, all of which need channel counts that are multiples of 4) and
  * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
  * gan_conv_plan_get reports the plan in effect (`thin` = 1 when mode 1 takes the vector-ALU path
  * for outputs of <= 4 channels, which has no plan).  Changing a plan changes the workspace size
@@ -240,7 +241,7 @@ int gan_get_exact_f32(void);
  * Each knob takes its initial value from an environment variable, read ONCE at the first call into
  * the library (no getenv on the launch path; a plan cannot change between a workspace query and the
  * call it sizes), and can be changed afterwards with gan_knob_set(name, value):
- *   "force_cfg"       GAN_HIP_FORCE_CFG=<0..6>   tile configuration of every contraction (-1: unset)
+ *   "force_cfg"       GAN_HIP_FORCE_CFG=<0..8>   tile configuration of every contraction (-1: unset)
  *   "force_splits"    GAN_HIP_FORCE_SPLITS=<n>   split-K factor of every contraction (0: unset)
  *   "no_thin"         GAN_HIP_NO_THIN=1          thin outputs (<= 4 channels / linear outputs) stay on the MFMA path
  *   "slow_gather"     GAN_HIP_SLOW_GATHER=1      general gather arithmetic in the split kernel (bit-identical)

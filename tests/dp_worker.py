@@ -78,7 +78,8 @@ def mark(msg):
 def run_gpu(out, rank, world):
     from test_gpu_dcgan import make_opts
     from gan_amd.dcgan import DCGAN
-    torch.cuda.set_device(0)
+    # gloo: every rank on the one visible GPU; nccl (RCCL): one GPU per rank
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("DP_BACKEND") == "nccl" else 0)
     data = np.load(os.path.join(out, "inputs.npz"))
     weights = {k[2:]: data[k] for k in data.files if k.startswith("w/")}
     opts = make_opts(seed=rank)                                  # different initial weights per rank
@@ -165,7 +166,12 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("DP_WORKER_STUCK_AFTER", "240")), exit=True)   # a stuck rank says where
     mark("joining the group")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DP_BACKEND", "gloo")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     mark("joined")
     try:
         {"cpu": run_cpu, "gpu": run_gpu, "train": run_train}[mode](out, rank, world)

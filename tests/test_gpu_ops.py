@@ -99,7 +99,7 @@ def test_conv2d_small(L, case):
     _conv_case(L, case)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_conv2d_every_tile_config_and_split(L, cfg, splits):
     _conv_case(L, (2, 12, 12, 8, 40, 5, 2, 'SAME'), cfg, splits)
@@ -191,7 +191,7 @@ def test_deconv2d_small(L, case):
     _deconv_case(L, case)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("splits", [1, 2])
 def test_deconv2d_every_tile_config_and_split(L, cfg, splits):
     _deconv_case(L, (2, 6, 6, 8, 36, 5, 2, 12, 12), cfg, splits)
