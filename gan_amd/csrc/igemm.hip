@@ -864,6 +864,12 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
         // enough blocks: 128x128 from 1024 rows on (the tuned DCGAN / CycleGAN plans agree)
         if (N >= 128 && M >= 1024) pl.cfg = 0;
         pl.cfg += kFirstSplitCfg;
+        // fewer 128x128 tiles than CUs: the k range is split anyway, so split it inside the workgroup first
+        // (two wave groups per tile, half the slabs); the tuner's choices on the DCGAN / CycleGAN shapes agree
+        if (pl.cfg == kFirstSplitCfg) {
+            const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * (mode == MODE_TPROP ? a.ncls : 1);
+            if (tiles < 256 && (K + BK - 1) / BK >= 24) pl.cfg = kFirstKg2Cfg;
+        }
     }
     int pinned_splits = 0;
     {

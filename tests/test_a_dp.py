@@ -259,7 +259,7 @@ def test_command_line_joins_a_two_rank_job(argv, tmp_path):
     procs, logs = [], []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo", DP_BACKEND=backend)
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
         logs.append(open(str(tmp_path / ("rank%d.log" % rank)), "wb"))
         procs.append(subprocess.Popen(cmd, env=env, cwd=os.path.dirname(HERE), stdout=logs[-1], stderr=subprocess.STDOUT))
     t0 = time.time()

@@ -67,14 +67,20 @@ def test_plan_pinning_is_host_side_bookkeeping():
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     assert get(0) == heur
     assert L.lib.gan_conv_plan_set(3, gp, 0, 1) != 0 and b"mode" in L.lib.gan_last_error()
-    assert L.lib.gan_conv_plan_set(0, gp, 7, 1) != 0
-    # configurations 4..6 are the split-bf16 kernels: the heuristic takes them for channel counts that are
+    assert L.lib.gan_conv_plan_set(0, gp, 9, 1) != 0
+    L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
+    # configurations 4..8 are the split-bf16 kernels (7, 8: split-K inside the workgroup): the heuristic takes them for channel counts that are
     # multiples of 4, a pin is honoured, and the exact-fp32 switch (or an odd channel count) maps them back
     assert heur[0] >= 4 and L.lib.gan_get_exact_f32() == 0
     L.check(L.lib.gan_conv_plan_set(0, gp, 5, 2))
     assert get(0)[:2] == (5, 2)
     L.lib.gan_set_exact_f32(1)
     assert get(0)[:2] == (1, 2) and L.lib.gan_get_exact_f32() == 1
+    L.lib.gan_set_exact_f32(0)
+    L.check(L.lib.gan_conv_plan_set(0, gp, 8, 2))
+    assert get(0)[:2] == (8, 2)
+    L.lib.gan_set_exact_f32(1)
+    assert get(0)[:2] == (1, 2)
     L.lib.gan_set_exact_f32(0)
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     godd = L.conv_geom(8, 16, 16, 6, 8, 8, 10, 5, 5, 2, 2, 1, 1)
