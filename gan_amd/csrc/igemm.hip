@@ -476,11 +476,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                         const float4 old = *o;
                         v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                     }
-                    if (epi_on) {
-                        const long e = (long)off + col;
-                        v.x = epi_apply(p.epi, v.x, e); v.y = epi_apply(p.epi, v.y, e + 1);
-                        v.z = epi_apply(p.epi, v.z, e + 2); v.w = epi_apply(p.epi, v.w, e + 3);
-                    }
+                    if (epi_on) v = epi_apply4(p.epi, v, (long)off + col);
                     *o = v;
                 }
             }
@@ -545,10 +541,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
                 const float4 o = reinterpret_cast<const float4*>(out)[i];
                 s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
             }
-            if (epi_on) {
-                s.x = epi_apply(epi, s.x, i * 4); s.y = epi_apply(epi, s.y, i * 4 + 1);
-                s.z = epi_apply(epi, s.z, i * 4 + 2); s.w = epi_apply(epi, s.w, i * 4 + 3);
-            }
+            if (epi_on) s = epi_apply4(epi, s, i * 4);
             reinterpret_cast<float4*>(out)[i] = s;
         }
     } else {
@@ -602,10 +595,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
             const float4 o = reinterpret_cast<const float4*>(out)[i4];
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
-        if (epi_active(epi)) {
-            s.x = epi_apply(epi, s.x, i4 * 4); s.y = epi_apply(epi, s.y, i4 * 4 + 1);
-            s.z = epi_apply(epi, s.z, i4 * 4 + 2); s.w = epi_apply(epi, s.w, i4 * 4 + 3);
-        }
+        if (epi_active(epi)) s = epi_apply4(epi, s, i4 * 4);
         reinterpret_cast<float4*>(out)[i4] = s;
     }
 }

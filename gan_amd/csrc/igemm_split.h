@@ -528,11 +528,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                         const float4 old = *o;
                         v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                     }
-                    if (epi_on) {
-                        const long e = (long)off + col;
-                        v.x = epi_apply(p.epi, v.x, e); v.y = epi_apply(p.epi, v.y, e + 1);
-                        v.z = epi_apply(p.epi, v.z, e + 2); v.w = epi_apply(p.epi, v.w, e + 3);
-                    }
+                    if (epi_on) v = epi_apply4(p.epi, v, (long)off + col);
                     *o = v;
                 }
             }

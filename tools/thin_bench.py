@@ -45,6 +45,18 @@ def main():
     for act, name in ((2, "lrelu"), (3, "tanh")):
         print("conv dgrad gated %-6s %.1f us" % (name, timeit(lambda: L.lib.gan_conv2d_dgrad_gated(
             gp, P(small), P(wt), P(big), P(gate), act, 0.2, 1.0, 0.0, wp, wn, st))))
+    # d_h0 forward: 3 -> 64 channels, output-bound (16.8 MB)
+    img = torch.randn(n, 64, 64, 3, device='cuda')
+    h0 = torch.empty(n, 32, 32, 64, device='cuda')
+    b64 = torch.randn(64, device='cuda')
+    for cfg in (1, 2):
+        L.knob_set("force_cfg", cfg)
+        L.knob_set("force_splits", 1)
+        print("conv fwd 3->64 cfg %d plain  %.1f us" % (cfg, timeit(lambda: L.lib.gan_conv2d_fwd(gp, P(img), P(wt), P(b64), P(h0), wp, wn, st))))
+        print("conv fwd 3->64 cfg %d lrelu  %.1f us" % (cfg, timeit(lambda: L.lib.gan_conv2d_fwd_act(
+            gp, P(img), P(wt), P(b64), P(h0), 2, 0.2, 1.0, 0.0, wp, wn, st))))
+    L.knob_set("force_cfg", -1)
+    L.knob_set("force_splits", 0)
     x = torch.randn(n, 64, 64, 3, device='cuda')
     y = torch.empty_like(x)
     print("act_fwd tanh on 3 MB  %.1f us" % timeit(lambda: L.lib.gan_act_fwd(P(x), P(y), x.numel(), 3, 0.0, 1.0, 0.0, st)))
