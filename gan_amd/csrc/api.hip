@@ -21,6 +21,9 @@ size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                    const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
+int run_igemm_geom_reflect(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
+                           int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
+                           const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
 int run_igemm_geom_epi(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                        const Epilogue& epi, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what);
 // elementwise.hip
@@ -135,6 +138,37 @@ extern "C" int gan_conv2d_fwd(const gan_conv_geom* g, const float* x, const floa
     if (int rc = conv_geom_check(g)) return rc;
     GAN_CHECK_ARG(x && w && y, "gan_conv2d_fwd: NULL tensor");
     return run_igemm_geom(MODE_FPROP, *g, x, w, y, bias, 0, g->cs, ws, ws_bytes, as_stream(stream), "gan_conv2d_fwd");
+}
+
+// ---------------------------------------------------------------------------- REFLECT padding folded into the gather
+extern "C" int gan_conv2d_fwd_reflect(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                                      void* ws, size_t ws_bytes, gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(x && w && y, "gan_conv2d_fwd_reflect: NULL tensor");
+    return run_igemm_geom_reflect(MODE_FPROP, *g, x, w, y, bias, 0, g->cs, ws, ws_bytes, as_stream(stream),
+                                  "gan_conv2d_fwd_reflect");
+}
+
+extern "C" int gan_conv2d_wgrad_reflect(const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
+                                        int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(x && dy && dw, "gan_conv2d_wgrad_reflect: NULL tensor");
+    hipStream_t st = as_stream(stream);
+    const char* what = "gan_conv2d_wgrad_reflect";
+    if (db == nullptr)
+        return run_igemm_geom_reflect(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, ws_bytes, st, what);
+    // bias gradient as in wgrad_with_bias: first stage ahead of the contraction, last stage on its slab reduction
+    const size_t off = align256(igemm_ws_bytes_geom(MODE_WGRAD, *g));
+    GAN_CHECK_ARG(ws && ws_bytes >= off, "%s: workspace of %zu bytes needed, %zu given", what, off, ws_bytes);
+    ColsumFinal job;
+    if (int rc = colsum_partial(dy, (long)g->n * g->hs * g->ws, g->cs, static_cast<char*>(ws) + off, ws_bytes - off, st, what, &job))
+        return rc;
+    job.out = db;
+    job.accumulate = accumulate;
+    int done = 0;
+    if (int rc = run_igemm_geom_reflect(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, off, st, what, &job, &done))
+        return rc;
+    return done ? 0 : colsum_final(job, st, what);
 }
 
 // ---------------------------------------------------------------------------- fused activation epilogues

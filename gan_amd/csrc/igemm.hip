@@ -80,7 +80,12 @@ struct IgemmArgs {
     FastDiv d_cb, d_cs, d_kw, d_hsws, d_ws;
     ClassInfo cls[kMaxClasses];
     Epilogue epi;  // applied where the final value is stored: here when splits == 1, else by the slab reduction
+    int reflect;   // FPROP / WGRAD: taps that fall outside the big image read its mirror image (tf.pad REFLECT
+                   // by pt / pl in front of a VALID convolution) instead of zeros
 };
+
+// index i of an image row / column of n pixels extended by reflection without repeating the edge (|i| < n beyond it)
+__device__ __forceinline__ int reflect_at(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // Raw gather load: masked-off lanes read element 0 of the tensor (always mapped); the zeroing
 // select happens when the registers are written to LDS one slice later, so nothing touches the
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
             const int tb = tapc - ta * (int)dTW.d;
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
-                const int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
-                const int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
+                int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                if (MODE == MODE_FPROP && p.reflect) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
                 const bool ok = kv && a_base[ps] >= 0 && (unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW;
                 const long off = ((long)(a_base[ps] + iy * SW + ix)) * SC + cc;
                 load_vec<VA>(a_reg[ps], p.a, off, ok);
@@ -223,7 +229,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
                 const int rem = uk - img * (int)p.d_hsws.d;
                 const int oy = fdiv(rem, p.d_ws);
                 const int ox = rem - oy * g.ws;
-                const int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
+                int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
+                if (p.reflect) { iy = reflect_at(iy, g.hb); ix = reflect_at(ix, g.wb); }
                 const bool ok = kv && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
                 const long off = ((long)((img * g.hb + iy) * g.wb + ix)) * g.cb + a_c;
                 load_vec<VA>(a_reg[ps], p.a, off, ok);
@@ -1069,6 +1076,7 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.accumulate = accumulate;
     r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1; r.vec_epilogue = 0;
     r.epi = no_epilogue();
+    r.reflect = 0;
     r.d_cb = make_fastdiv((unsigned)g.cb);
     r.d_cs = make_fastdiv((unsigned)g.cs);
     r.d_kw = make_fastdiv((unsigned)g.kw);
@@ -1137,6 +1145,20 @@ int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                    const ColsumFinal* tail, int* tail_done) {
     return run_igemm(mode, make_args(mode, g, a, b, out, bias, accumulate), out_c, ws, ws_bytes, s, what, tail, tail_done);
+}
+
+// Reflecting taps: the geometry's pad_before (pt, pl) says how far the image is extended by reflection on each side.
+// Forward and weight-gradient contractions only (they gather from the big image).
+int run_igemm_geom_reflect(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
+                           int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
+                           const ColsumFinal* tail, int* tail_done) {
+    GAN_CHECK_ARG(mode == MODE_FPROP || mode == MODE_WGRAD, "%s: reflection applies to forward and weight gradient", what);
+    GAN_CHECK_ARG(g.pt < g.hb && g.pl < g.wb && (g.hs - 1) * g.sh + g.kh - 1 - g.pt < 2 * g.hb - 1 &&
+                  (g.ws - 1) * g.sw + g.kw - 1 - g.pl < 2 * g.wb - 1,
+                  "%s: REFLECT padding must be smaller than the image", what);
+    IgemmArgs args = make_args(mode, g, a, b, out, bias, accumulate);
+    args.reflect = 1;
+    return run_igemm(mode, args, out_c, ws, ws_bytes, s, what, tail, tail_done);
 }
 
 // The same with a fused epilogue (activation behind the output, or the activation derivative of a gate tensor).

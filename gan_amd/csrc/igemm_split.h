@@ -217,11 +217,22 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             const int sgn = (MODE == MODE_TPROP) ? -1 : 1;
             const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((sgn * (ta * SW + tb) * SC + cc0) * 4);
             const bool kv = (int)k0 + t_kq * 4 < kend;
+            if (MODE == MODE_FPROP && p.reflect) {
+                // mirrored taps: the offset is no longer base + per-slice constant
+                const unsigned uc = (unsigned)__builtin_amdgcn_readfirstlane(cc0 * 4) + t_kq * 16;
 #pragma unroll
-            for (int ps = 0; ps < A_PASS; ++ps) {
-                const int iy = a_y0[ps] + sgn * ta, ix = a_x0[ps] + sgn * tb;
-                const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
-                ld4(rsrc_a, ok ? a_rb[ps] + u : kOutOfRange, a_reg[ps]);
+                for (int ps = 0; ps < A_PASS; ++ps) {
+                    const int iy = reflect_at(a_y0[ps] + ta, SH), ix = reflect_at(a_x0[ps] + tb, SW);
+                    const bool ok = kv & (a_base[ps] >= 0);
+                    ld4(rsrc_a, ok ? (unsigned)((a_base[ps] + iy * SW + ix) * SC) * 4u + uc : kOutOfRange, a_reg[ps]);
+                }
+            } else {
+#pragma unroll
+                for (int ps = 0; ps < A_PASS; ++ps) {
+                    const int iy = a_y0[ps] + sgn * ta, ix = a_x0[ps] + sgn * tb;
+                    const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
+                    ld4(rsrc_a, ok ? a_rb[ps] + u : kOutOfRange, a_reg[ps]);
+                }
             }
         } else if constexpr (A_TRANS) {
             const int k = kt * BK + t_kq * 4;
@@ -233,8 +244,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             const int tb = tapc - ta * (int)dTW.d;
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
-                const int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
-                const int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
+                int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                if (MODE == MODE_FPROP && p.reflect) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
                 const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
                 const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
                 ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
@@ -249,13 +261,22 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             const int oy = fdiv(rem, p.d_ws);
             const int ox = rem - oy * g.ws;
             const int iy = oy * g.sh + a_kh - g.pt, ix0 = ox * g.sw + a_kw - g.pl;
-            const bool rowok = kv & ((unsigned)iy < (unsigned)g.hb);
-            const unsigned off0 = (unsigned)(((img * g.hb + iy) * g.wb + ix0) * g.cb + a_c) * 4u;
-            const unsigned step = (unsigned)(g.sw * g.cb) * 4u;
+            if (p.reflect) {
+                const unsigned rowb = (unsigned)((img * g.hb + reflect_at(iy, g.hb)) * g.wb);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = rowok & ((unsigned)(ix0 + j * g.sw) < (unsigned)g.wb);
-                ld2(rsrc_a, ok ? off0 + j * step : kOutOfRange, a_reg[j]);
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = reflect_at(ix0 + j * g.sw, g.wb);
+                    ld2(rsrc_a, kv ? (unsigned)((rowb + ix) * g.cb + a_c) * 4u : kOutOfRange, a_reg[j]);
+                }
+            } else {
+                const bool rowok = kv & ((unsigned)iy < (unsigned)g.hb);
+                const unsigned off0 = (unsigned)(((img * g.hb + iy) * g.wb + ix0) * g.cb + a_c) * 4u;
+                const unsigned step = (unsigned)(g.sw * g.cb) * 4u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rowok & ((unsigned)(ix0 + j * g.sw) < (unsigned)g.wb);
+                    ld2(rsrc_a, ok ? off0 + j * step : kOutOfRange, a_reg[j]);
+                }
             }
         } else {
 #pragma unroll
@@ -267,7 +288,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 const int rem = uk - img * (int)p.d_hsws.d;
                 const int oy = fdiv(rem, p.d_ws);
                 const int ox = rem - oy * g.ws;
-                const int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
+                int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
+                if (p.reflect) { iy = reflect_at(iy, g.hb); ix = reflect_at(ix, g.wb); }
                 const bool ok = kv & ((unsigned)iy < (unsigned)g.hb) & ((unsigned)ix < (unsigned)g.wb);
                 const unsigned off = (unsigned)(((img * g.hb + iy) * g.wb + ix) * g.cb + a_c) * 4u;
                 ld2(rsrc_a, ok ? off : kOutOfRange, a_reg[j]);

@@ -54,11 +54,12 @@ def generator_resnet(image, options, reuse=False, name="generator"):
             resBN2 = batch_norm(name=name + '_bn2')
             p = int((ks - 1) / 2)
             x, skip = ops.fork(x)       # the block's input feeds the convolutions and the skip connection
-            y = ops.reflect_pad(x, p)
-            y = resBN1(conv2d(y, dim, ks, ks, s, s, padding='VALID', name=name + '_c1'), act='relu')
-            y = ops.reflect_pad(y, p)
+            # tf.pad(x, REFLECT by p) + VALID conv (cyclegan_module.py:106-109): the padding is folded into the
+            # convolution's gather (padding='REFLECT'), no padded copy is written
+            assert s == 1 and p * 2 + 1 == ks
+            y = resBN1(conv2d(x, dim, ks, ks, s, s, padding='REFLECT', name=name + '_c1'), act='relu')
             # resBN2(...) + x, the residual add fused into the normalisation kernel
-            return resBN2(conv2d(y, dim, ks, ks, s, s, padding='VALID', name=name + '_c2'), residual=skip)
+            return resBN2(conv2d(y, dim, ks, ks, s, s, padding='REFLECT', name=name + '_c2'), residual=skip)
 
         g_e1_bn = batch_norm(name='g_e1_bn')
         g_e2_bn = batch_norm(name='g_e2_bn')
@@ -71,8 +72,7 @@ def generator_resnet(image, options, reuse=False, name="generator"):
         s2 = int(s / 2)
         # the fast-neural-style layout the reference cites (cyclegan_module.py:121-122): 7x7 stem, two stride-2
         # convs down, nine residual blocks, two stride-2 transposed convs up, 7x7 head
-        c0 = ops.reflect_pad(image, 3)
-        c1 = g_e1_bn(conv2d(c0, options.gf_dim, 7, 7, 1, 1, padding='VALID', name='g_e1_c'), act='relu')
+        c1 = g_e1_bn(conv2d(image, options.gf_dim, 7, 7, 1, 1, padding='REFLECT', name='g_e1_c'), act='relu')
         c2 = g_e2_bn(conv2d(c1, options.gf_dim * 2, 3, 3, 2, 2, name='g_e2_c'), act='relu')
         c3 = g_e3_bn(conv2d(c2, options.gf_dim * 4, 3, 3, 2, 2, name='g_e3_c'), act='relu')
         # nine residual blocks
@@ -84,8 +84,7 @@ def generator_resnet(image, options, reuse=False, name="generator"):
         d1 = g_d1_bn(d1, act='relu')
         d2 = deconv2d(d1, [options.batch_size, s, s, options.gf_dim], 3, 3, 2, 2, name='g_d2_dc')
         d2 = g_d2_bn(d2, act='relu')
-        d2 = ops.reflect_pad(d2, 3)
-        pred = conv2d(d2, options.output_c_dim, 7, 7, 1, 1, padding='VALID', name='g_pred_c')
+        pred = conv2d(d2, options.output_c_dim, 7, 7, 1, 1, padding='REFLECT', name='g_pred_c')
         pred = g_pred_bn(pred, act='tanh')
 
         return pred

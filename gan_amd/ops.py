@@ -76,12 +76,18 @@ def _conv_geom(n, h, w, c_big, c_small, k_h, k_w, d_h, d_w, padding, small_hw=No
     if padding == 'SAME':
         hs, pt = same_pad(h, k_h, d_h)
         ws, pl = same_pad(w, k_w, d_w)
+    elif padding == 'REFLECT':
+        if k_h % 2 == 0 or k_w % 2 == 0 or d_h != 1 or d_w != 1:
+            raise ValueError("REFLECT padding needs odd filter sizes and stride 1 (got %dx%d, stride %dx%d)" % (k_h, k_w, d_h, d_w))
+        hs, ws, pt, pl = h, w, (k_h - 1) // 2, (k_w - 1) // 2
+        if pt >= h or pl >= w:
+            raise ValueError("REFLECT padding of %dx%d does not fit a %dx%d image" % (pt, pl, h, w))
     elif padding == 'VALID':
         if h < k_h or w < k_w:
             raise ValueError("VALID convolution: %dx%d filter larger than %dx%d input" % (k_h, k_w, h, w))
         hs, ws, pt, pl = (h - k_h) // d_h + 1, (w - k_w) // d_w + 1, 0, 0
     else:
-        raise ValueError("padding must be 'SAME' or 'VALID', got %r" % (padding,))
+        raise ValueError("padding must be 'SAME', 'VALID' or 'REFLECT', got %r" % (padding,))
     if small_hw is not None and tuple(small_hw) != (hs, ws):
         raise ValueError("conv2d_transpose: output_shape %s does not match input spatial size %s "
                          "(a stride-%dx%d SAME conv of the output gives %s)"
@@ -164,11 +170,17 @@ def _through_own_activation(ctx, y, dy):
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, token, w, b, g, act_tok, in_tok):
+    def forward(ctx, x, token, w, b, g, act_tok, in_tok, reflect=False):
         x = _dense(x)
         y = torch.empty((g.n, g.hs, g.ws, g.cs), dtype=torch.float32, device=x.device)
         wp, wn = _conv_ws(g)
-        if act_tok is None:
+        ctx.reflect = reflect
+        if reflect:
+            if act_tok is not None or in_tok is not None:
+                raise ValueError("conv2d: REFLECT padding does not combine with a fused activation")
+            check(lib.gan_conv2d_fwd_reflect(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
+            ctx.save_for_backward(x)
+        elif act_tok is None:
             check(lib.gan_conv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
             ctx.save_for_backward(x)
         else:
@@ -191,18 +203,28 @@ class _Conv2dFn(torch.autograd.Function):
             dw, acc = w.grad_target()
             db, accb = b.grad_target()
             assert acc == accb
-            check(lib.gan_conv2d_wgrad(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
+            wgrad = lib.gan_conv2d_wgrad_reflect if ctx.reflect else lib.gan_conv2d_wgrad
+            check(wgrad(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if ctx.in_tok is None:
+            if ctx.reflect:
+                # input gradient of the VALID convolution on the reflect-padded image, then folded back onto the image
+                gp = _lib.conv_geom(g.n, g.hb + 2 * g.pt, g.wb + 2 * g.pl, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, 1, 1, 0, 0)
+                wpp, wnp = _conv_ws(gp)
+                dxp = torch.empty((g.n, gp.hb, gp.wb, g.cb), dtype=torch.float32, device=x.device)
+                check(lib.gan_conv2d_dgrad(ctypes.byref(gp), ptr(dy), ptr(w.data), ptr(dxp), wpp, wnp, stream()))
+                if g.pt != g.pl:
+                    raise ValueError("REFLECT padding: square filters only")
+                check(lib.gan_reflect_pad_bwd(ptr(dxp), ptr(dx), g.n, g.hb, g.wb, g.cb, g.pt, stream()))
+            elif ctx.in_tok is None:
                 check(lib.gan_conv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
             else:       # x is the activated output of the layer below: hand it the gradient in front of its activation
                 code, param, scale, shift = ctx.in_tok.spec
                 check(lib.gan_conv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param, scale,
                                                  shift, wp, wn, stream()))
                 ctx.in_tok.grad_ptr = dx.data_ptr()
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class _Deconv2dFn(torch.autograd.Function):
@@ -304,7 +326,10 @@ def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding=
         autotune.tune_geometry(g)
     spec = _act_spec(act, act_param, act_scale, act_shift)
     tok = _ActToken(spec) if spec is not None else None
-    y = _Conv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_))
+    if padding == 'REFLECT' and autotune.enabled():
+        autotune.tune_geometry(_lib.conv_geom(g.n, g.hb + 2 * g.pt, g.wb + 2 * g.pl, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, 1, 1, 0, 0))
+    y = _Conv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_),
+                        padding == 'REFLECT')
     if tok is not None:
         y._gan_act = tok
     return y

@@ -130,3 +130,59 @@ def test_fused_activation_protocol_equals_the_unfused_composition(consumer):
     assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l1))
     assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
     assert float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx1.abs().max())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 48, 3), (1, 20, 12, 3, 8, 7), (1, 12, 12, 16, 3, 7), (2, 9, 11, 6, 10, 3)])
+def test_reflect_padding_folded_into_the_gather(case):
+    """gan_conv2d_fwd_reflect / _wgrad_reflect on the unpadded image against the float64 oracle's
+    conv2d(pad(x, REFLECT), VALID) and its filter gradient; ops.conv2d(padding='REFLECT') against
+    ops.conv2d(ops.reflect_pad(x), padding='VALID') including the input gradient."""
+    from gan_amd import _lib as L
+    from gan_amd import ops, variables as V
+    from gan_amd.optim import AdamOptimizer
+    from gpu_util import assert_close, dev, host
+    n, h, w_, cb, cs, k = case
+    p = (k - 1) // 2
+    g = L.conv_geom(n, h, w_, cb, h, w_, cs, k, k, 1, 1, p, p)
+    gp = ctypes.byref(g)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, h, w_, cb)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cb, cs)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cs).astype(np.float32)
+    dy = rng.standard_normal((n, h, w_, cs)).astype(np.float32)
+    d = np.float64
+    xp = np.pad(x.astype(d), ((0, 0), (p, p), (p, p), (0, 0)), mode='reflect')
+    x_d, w_d, b_d, dy_d = dev(x), dev(wt), dev(b), dev(dy)
+    y = torch.empty(n, h, w_, cs, device='cuda')
+    wp, wn = L.workspace(int(L.lib.gan_conv_workspace_bytes(gp)))
+    L.check(L.lib.gan_conv2d_fwd_reflect(gp, L.ptr(x_d), L.ptr(w_d), L.ptr(b_d), L.ptr(y), wp, wn, L.stream()))
+    assert_close(host(y), T.conv2d_forward(xp, wt.astype(d), 1, 1, 'VALID') + b, "conv2d_fwd_reflect")
+    dw, db = torch.empty(k, k, cb, cs, device='cuda'), torch.empty(cs, device='cuda')
+    L.check(L.lib.gan_conv2d_wgrad_reflect(gp, L.ptr(x_d), L.ptr(dy_d), L.ptr(dw), L.ptr(db), 0, wp, wn, L.stream()))
+    assert_close(host(dw), T.conv2d_backward_filter(xp, dy.astype(d), k, k, 1, 1, 'VALID'), "conv2d_wgrad_reflect")
+    assert_close(host(db), dy.astype(d).sum(axis=(0, 1, 2)), "bias gradient")
+    # the Python op, both ways
+    res = []
+    for folded in (True, False):
+        store = V.VariableStore(device='cuda', seed=3)
+        with V.use_store(store):
+            def net(inp):
+                if folded:
+                    o = ops.conv2d(inp, cs, k, k, 1, 1, padding='REFLECT', name='c')
+                else:
+                    o = ops.conv2d(ops.reflect_pad(inp, p), cs, k, k, 1, 1, padding='VALID', name='c')
+                return ops.mse_const_mean(o, 0.1)
+            net(x_d)
+            group = store.pack('n', store.trainable_variables())
+            opt = AdamOptimizer(1e-3, beta1=0.5).attach(group)
+            opt.begin()
+            xin = x_d.clone().requires_grad_(True)
+            loss = net(xin)
+            ops.backward(loss)
+            opt.finish_grads()
+            torch.cuda.synchronize()
+            res.append((float(loss.detach()), group.grads.clone(), xin.grad.clone()))
+    (l0, g0, dx0), (l1, g1, dx1) = res
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l1))
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx1.abs().max())
