@@ -64,6 +64,7 @@ Knobs& knobs() {
         r.scalar_epilogue = getenv("GAN_HIP_SCALAR_EPILOGUE") != nullptr;
         r.three_launch_bn = getenv("GAN_HIP_THREE_LAUNCH_BN") != nullptr;
         r.separate_colsum = getenv("GAN_HIP_SEPARATE_COLSUM") != nullptr;
+        r.launch_order_grid = env_flag("GAN_HIP_LAUNCH_ORDER_GRID");
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
         return r;
     }();
@@ -484,6 +485,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "scalar_epilogue")) k.scalar_epilogue = value != 0;
     else if (!strcmp(name, "three_launch_bn")) k.three_launch_bn = value != 0;
     else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
+    else if (!strcmp(name, "launch_order_grid")) k.launch_order_grid = value != 0;
     else return fail("gan_knob_set: unknown knob '%s'", name);
     return 0;
 }

@@ -82,7 +82,46 @@ struct IgemmArgs {
     Epilogue epi;  // applied where the final value is stored: here when splits == 1, else by the slab reduction
     int reflect;   // FPROP / WGRAD: taps that fall outside the big image read its mirror image (tf.pad REFLECT
                    // by pt / pl in front of a VALID convolution) instead of zeros
+    int grid_mt, grid_nt, grid_z;  // row tiles, column tiles, (parity classes x k splits) of the one-dimensional grid
+    int xcd_order;                 // launch position -> tile through tile_of_workgroup's XCD-aware order
 };
+
+// Which tile a workgroup computes.  The grid is one-dimensional.  The hardware hands workgroups to the 8 XCDs
+// round robin in launch order (position L runs on XCD L % 8) and every XCD has an L2 of its own, so tiles that
+// read the same operand bytes should sit on ONE XCD at the same time.  Launch positions are therefore mapped to
+// work indices such that each XCD receives one contiguous range of them, and the work index is decoded with the
+// operand-sharing axis fastest:
+//   FPROP / TPROP  all parity classes, k splits and column tiles of one row tile are neighbours (they gather the
+//                  same neighbourhood of the image, tap by tap);
+//   WGRAD          all row and column tiles of one k split are neighbours (a k split is a range of images, which
+//                  every filter tap reads, shifted).
+struct TileId { int mt, nt, z; };
+template <int MODE>
+__device__ __forceinline__ TileId tile_of_workgroup(const IgemmArgs& p) {
+    const unsigned MT = (unsigned)p.grid_mt, NT = (unsigned)p.grid_nt, Z = (unsigned)p.grid_z;
+    const unsigned L = blockIdx.x;
+    unsigned w = L;
+    if (p.xcd_order) {
+        const unsigned T = MT * NT * Z;
+        const unsigned per = (T + 7u) >> 3;                  // work items of a "tall" XCD
+        const unsigned tall = (T & 7u) ? (T & 7u) : 8u;      // XCDs that receive `per` items (the rest per - 1)
+        const unsigned xcd = L & 7u, loc = L >> 3;
+        w = xcd < tall ? xcd * per + loc : tall * per + (xcd - tall) * (per - 1u) + loc;
+    }
+    TileId t;
+    if constexpr (MODE == MODE_WGRAD) {
+        t.mt = (int)(w % MT);
+        const unsigned r = w / MT;
+        t.nt = (int)(r % NT);
+        t.z = (int)(r / NT);
+    } else {
+        t.z = (int)(w % Z);
+        const unsigned r = w / Z;
+        t.nt = (int)(r % NT);
+        t.mt = (int)(r / NT);
+    }
+    return t;
+}
 
 // index i of an image row / column of n pixels extended by reflection without repeating the edge (|i| < n beyond it)
 __device__ __forceinline__ int reflect_at(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -120,8 +159,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int split = blockIdx.z % p.splits;
-    const int ci = blockIdx.z / p.splits;
+    const TileId tile = tile_of_workgroup<MODE>(p);
+    const int split = tile.z % p.splits;
+    const int ci = tile.z / p.splits;
     const gan_conv_geom& g = p.g;
 
     int M, N, K;
@@ -135,9 +175,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     } else {
         M = p.M; N = p.N; K = p.K;
     }
-    const int m0 = blockIdx.x * BM;
+    const int m0 = tile.mt * BM;
     if (m0 >= M) return;  // block-uniform: smaller parity classes have fewer row tiles
-    const int n0 = blockIdx.y * BN;
+    const int n0 = tile.nt * BN;
     const int nkt = (K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nkt, kt0 + p.kt_per_split);
@@ -1030,7 +1070,11 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         a.vec_epilogue = ((n_out & 3) == 0 && (pl.out_elems & 3) == 0 && aligned16(a.out) && aligned16(final_out) &&
                           (bias == nullptr || aligned16(bias)) && !knobs().scalar_epilogue) ? 1 : 0;
     }
-    dim3 grid(pl.mt, pl.nt, pl.splits * a.ncls);
+    a.grid_mt = pl.mt;
+    a.grid_nt = pl.nt;
+    a.grid_z = pl.splits * a.ncls;
+    a.xcd_order = knobs().launch_order_grid ? 0 : 1;
+    dim3 grid((unsigned)(pl.mt * pl.nt * pl.splits * a.ncls));
     switch (mode) {
         case MODE_FPROP: launch_cfg<MODE_FPROP>(a, pl, grid, s); break;
         case MODE_TPROP: launch_cfg<MODE_TPROP>(a, pl, grid, s); break;

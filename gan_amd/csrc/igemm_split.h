@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int split = blockIdx.z % p.splits;
-    const int ci = blockIdx.z / p.splits;
+    const TileId tile = tile_of_workgroup<MODE>(p);
+    const int split = tile.z % p.splits;
+    const int ci = tile.z / p.splits;
     const gan_conv_geom& g = p.g;
 
     int M, N, K;
@@ -98,9 +99,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     } else {
         M = p.M; N = p.N; K = p.K;
     }
-    const int m0 = blockIdx.x * BM;
+    const int m0 = tile.mt * BM;
     if (m0 >= M) return;  // block-uniform
-    const int n0 = blockIdx.y * BN;
+    const int n0 = tile.nt * BN;
     const int nkt = (K + BK - 1) / BK;
     // the workgroup's k range, divided over its k groups; every group runs `per_group` slices (a group whose
     // share is shorter multiplies zeros at the end: the barriers must match)

@@ -259,6 +259,9 @@ int gan_get_exact_f32(void);
  *   "three_launch_bn" GAN_HIP_THREE_LAUNCH_BN=1  small batch norms (<= 1024 rows per group) on the general path
  *   "separate_colsum" GAN_HIP_SEPARATE_COLSUM=1  bias gradients as two launches after the weight gradient
  *                                                (bit-identical to the default, fused placement)
+ *   "launch_order_grid" GAN_HIP_LAUNCH_ORDER_GRID=1  contraction tiles in plain launch order instead of the
+ *                                                order that keeps tiles sharing operand bytes on one XCD
+ *                                                (bit-identical; for traffic measurements)
  * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe
  * against concurrent calls into the library. */
 int gan_knob_set(const char* name, int value);

@@ -556,6 +556,39 @@ def test_split_kernel_gather_variants_agree_bitwise(L, case, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", [(3, 14, 16, 32, 80, 5, 2), (1, 17, 13, 16, 144, 3, 1), (5, 15, 15, 3, 24, 5, 2),
+                                  (2, 9, 11, 21, 74, 5, 2), (2, 16, 16, 64, 128, 5, 2)])
+@pytest.mark.parametrize("cfg", [None, 2, 6, 8])
+def test_xcd_grouped_tile_order_is_a_permutation_of_the_launch_order(L, case, cfg):
+    """The contraction kernels map launch positions to tiles so that tiles sharing operand bytes run on one XCD.
+    The map must be a bijection for every grid size (also when the tile count is no multiple of 8, and with
+    parity classes of unequal size): each tile computed exactly once gives bit-identical outputs to the plain
+    launch order; a tile computed twice or never would leave poison or a stale value in the output."""
+    from gpu_util import geom_for
+    n, h, w, cb, cs, k, s = case
+    g = geom_for(n, h, w, cb, cs, k, s, 'SAME')
+    gp = ctypes.byref(g)
+    x = torch.randn(n, h, w, cb, device='cuda')
+    wt = torch.randn(k, k, cb, cs, device='cuda') * 0.05
+    dy = torch.randn(n, g.hs, g.ws, cs, device='cuda')
+    if cfg is not None and not (cfg >= 4 and (cb % 4 or cs % 4)):
+        L.knob_set("force_cfg", cfg)
+    L.knob_set("no_thin", 1)
+    outs = []
+    for plain in (1, 0):
+        L.knob_set("launch_order_grid", plain)
+        y, dx, dw = (torch.full_like(t, float('nan')) for t in (dy, x, wt))
+        wp, wn = _ws(L, g)
+        st = L.stream()
+        L.check(L.lib.gan_conv2d_fwd(gp, L.ptr(x), L.ptr(wt), None, L.ptr(y), wp, wn, st))
+        L.check(L.lib.gan_conv2d_dgrad(gp, L.ptr(dy), L.ptr(wt), L.ptr(dx), wp, wn, st))
+        L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(x), L.ptr(dy), L.ptr(dw), None, 0, wp, wn, st))
+        torch.cuda.synchronize()
+        outs.append((y, dx, dw))
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("case,accumulate", [((4, 16, 16, 64, 128, 5, 2), 0), ((2, 12, 12, 3, 16, 5, 2), 1),
                                              ((64, 8, 8, 16, 10, 3, 1), 0)])
 def test_bias_gradient_carried_by_the_slab_reduction_is_bit_identical(L, case, accumulate, monkeypatch):
