@@ -32,6 +32,8 @@ MAX_SLAB_BYTES = 256 << 20
 MIN_GAIN = 0.03      # a candidate must beat the heuristic by this fraction to replace it
 FINALISTS = 5        # candidates of the quick scan that are timed again
 FINAL_REPS = 12
+ORDER_STRIDE = 16    # plan_set's cfg = tile configuration + 16 * tile order (0: the library's choice)
+ORDER_GAIN = 0.02    # an explicit tile order must beat the library's choice by this fraction
 
 
 def enable(flag=True):
@@ -151,11 +153,20 @@ def tune_geometry(g, reps=3, verbose=False):
                 us = min(_time(run, FINAL_REPS), _time(run, FINAL_REPS))
                 if us < best[2]:
                     best = (cfg, splits, us)
-            if best[:2] != heur and best[2] < base * (1.0 - MIN_GAIN):
+            if not (best[:2] != heur and best[2] < base * (1.0 - MIN_GAIN)):
+                best = (heur[0], heur[1], base)
+            # stage 3: the tile order (which tiles share an XCD's L2) of the chosen plan.  Fewer bytes over the
+            # fabric are not always less time, so the clock decides; the library's choice stays unless beaten.
+            tile_cfg, splits = best[0] % ORDER_STRIDE, best[1]
+            for order in (1, 2, 3):
+                check(lib.gan_conv_plan_set(mode, gp, tile_cfg + ORDER_STRIDE * order, splits))
+                us = min(_time(run, FINAL_REPS), _time(run, FINAL_REPS))
+                if us < best[2] * (1.0 - ORDER_GAIN):
+                    best = (tile_cfg + ORDER_STRIDE * order, splits, us)
+            if best[:2] != heur:
                 check(lib.gan_conv_plan_set(mode, gp, best[0], best[1]))
             else:
                 check(lib.gan_conv_plan_set(mode, gp, -1, 1))
-                best = (heur[0], heur[1], base)
         res[mode] = (best[0], best[1], best[2], base)
         if verbose:
             print("autotune %s mode %d: cfg %d splits %d %.1f us (heuristic cfg %d splits %d %.1f us)"
@@ -170,6 +181,34 @@ def tune_linear(rows, in_dim, out_dim, **kw):
     g = ConvGeom()
     check(lib.gan_linear_as_conv_geom(rows, in_dim, out_dim, ctypes.byref(g)))
     return tune_geometry(g, **kw)
+
+
+def save(path):
+    """Write the tuned plans as JSON: a later process pins the same plans with load() instead of timing again
+    (and then sums split-K partial results in the same order, i.e. reproduces this process bit for bit)."""
+    import json
+    with open(path, "w") as f:
+        json.dump([{"geom": list(k), "plans": {str(m): list(v) for m, v in res.items()}} for k, res in _done.items()], f)
+
+
+def load(path):
+    """Pin the plans written by save().  Geometries not in the file are tuned on first use as usual."""
+    import json
+    with open(path) as f:
+        rows = json.load(f)
+    for row in rows:
+        g = ConvGeom(*row["geom"])
+        res = {}
+        for m, (cfg, splits, us, heur_us) in row["plans"].items():
+            c, s, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(lib.gan_conv_plan_set(int(m), ctypes.byref(g), -1, 1))
+            check(lib.gan_conv_plan_get(int(m), ctypes.byref(g), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+            if not thin.value and (c.value, s.value) != (cfg, splits):
+                check(lib.gan_conv_plan_set(int(m), ctypes.byref(g), int(cfg), int(splits)))
+            res[int(m)] = (int(cfg), int(splits), float(us), float(heur_us))
+        _done[g.key()] = res
+    for fn in _listeners:
+        fn()
 
 
 def reset():

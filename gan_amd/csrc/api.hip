@@ -64,7 +64,7 @@ Knobs& knobs() {
         r.scalar_epilogue = getenv("GAN_HIP_SCALAR_EPILOGUE") != nullptr;
         r.three_launch_bn = getenv("GAN_HIP_THREE_LAUNCH_BN") != nullptr;
         r.separate_colsum = getenv("GAN_HIP_SEPARATE_COLSUM") != nullptr;
-        r.launch_order_grid = env_flag("GAN_HIP_LAUNCH_ORDER_GRID");
+        r.tile_order = env_int("GAN_HIP_TILE_ORDER", 0);
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
         return r;
     }();
@@ -460,7 +460,8 @@ static int plan_mode_check(const char* what, int mode) {
 extern "C" int gan_conv_plan_set(int mode, const gan_conv_geom* g, int cfg, int splits) {
     if (int rc = plan_mode_check("gan_conv_plan_set", mode)) return rc;
     if (int rc = conv_geom_check(g)) return rc;
-    GAN_CHECK_ARG(cfg < 9, "gan_conv_plan_set: tile configuration must be 0..8 (or negative to unpin)");
+    GAN_CHECK_ARG(cfg < 0 || (cfg % 16 < 9 && cfg / 16 <= 3),
+                  "gan_conv_plan_set: cfg must be a tile configuration 0..8 plus 16 x a tile order 0..3 (or negative to unpin)");
     GAN_CHECK_ARG(cfg < 0 || (splits >= 1 && splits <= 512), "gan_conv_plan_set: split factor must be in 1..512");
     return plan_set(mode, *g, cfg, splits);
 }
@@ -485,7 +486,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "scalar_epilogue")) k.scalar_epilogue = value != 0;
     else if (!strcmp(name, "three_launch_bn")) k.three_launch_bn = value != 0;
     else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
-    else if (!strcmp(name, "launch_order_grid")) k.launch_order_grid = value != 0;
+    else if (!strcmp(name, "tile_order")) k.tile_order = value;
     else return fail("gan_knob_set: unknown knob '%s'", name);
     return 0;
 }

@@ -227,7 +227,11 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
  * 6: 64x64, 7: 128x128 and 8: 128x64 with the split-K halved inside the workgroup -- two groups of four waves
  * share one output tile --, all of which need channel counts that are multiples of 4) and
  * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
- * gan_conv_plan_get reports the plan in effect (`thin` = 1 when mode 1 takes the vector-ALU path
+ * cfg may carry a tile order as well, cfg = tile configuration + 16 * order: which output tile a workgroup
+ * computes as a function of its launch position (workgroups go to the 8 XCDs round robin, each XCD has its own
+ * L2): 0 chosen by the library, 1 launch order, 2 all k splits / parity classes / column tiles of a row tile side
+ * by side on one XCD, 3 all tiles of one k range side by side.  Results do not depend on it.
+ * gan_conv_plan_get reports the plan in effect (cfg in the same encoding) (`thin` = 1 when mode 1 takes the vector-ALU path
  * for outputs of <= 4 channels, which has no plan).  Changing a plan changes the workspace size
  * gan_conv_workspace_bytes reports.  gan_linear_as_conv_geom yields the geometry under which
  * the linear entry points look their plan up. */
@@ -259,9 +263,10 @@ int gan_get_exact_f32(void);
  *   "three_launch_bn" GAN_HIP_THREE_LAUNCH_BN=1  small batch norms (<= 1024 rows per group) on the general path
  *   "separate_colsum" GAN_HIP_SEPARATE_COLSUM=1  bias gradients as two launches after the weight gradient
  *                                                (bit-identical to the default, fused placement)
- *   "launch_order_grid" GAN_HIP_LAUNCH_ORDER_GRID=1  contraction tiles in plain launch order instead of the
- *                                                order that keeps tiles sharing operand bytes on one XCD
- *                                                (bit-identical; for traffic measurements)
+ *   "tile_order"      GAN_HIP_TILE_ORDER=<0..3>  which tile a contraction workgroup computes: 0 chosen per launch so
+ *                                                that tiles sharing operand bytes run on one XCD, 1 plain launch
+ *                                                order, 2 grouped by row tile, 3 grouped by k range (bit-identical
+ *                                                results; for traffic measurements)
  * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe
  * against concurrent calls into the library. */
 int gan_knob_set(const char* name, int value);

@@ -1,6 +1,7 @@
 """GPU parity of every C-ABI entry point against the float64 numpy oracle, on identical seeded
 inputs.  Calls go through ctypes into libgan_hip.so (torch only owns the device memory)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -521,6 +522,20 @@ def test_autotuned_plans_keep_parity(L):
         _conv_case(L, case)
         lin = autotune.tune_linear(8, 40, 24, reps=2)
         assert set(lin) == {0, 1, 2}
+        # saved plans are pinned again by load(), without timing anything
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(), "plans.json")
+        autotune.save(path)
+        before = autotune.report()
+        autotune.reset()
+        autotune.load(path)
+        assert autotune.report() == before
+        c, sp, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for mode in (0, 1, 2):
+            L.check(L.lib.gan_conv_plan_get(mode, ctypes.byref(g), ctypes.byref(c), ctypes.byref(sp), ctypes.byref(thin)))
+            want = before[g.key()][mode][:2]      # the library rounds a split request to equal k ranges
+            assert thin.value or (c.value == want[0] and 0 < sp.value <= want[1])
+        _conv_case(L, case)
     finally:
         autotune.reset()
     assert autotune.report() == {}
@@ -575,8 +590,19 @@ def test_xcd_grouped_tile_order_is_a_permutation_of_the_launch_order(L, case, cf
         L.knob_set("force_cfg", cfg)
     L.knob_set("no_thin", 1)
     outs = []
-    for plain in (1, 0):
-        L.knob_set("launch_order_grid", plain)
+    for order in (1, 0, 2, 3, -2):
+        if order >= 0:
+            L.knob_set("tile_order", order)
+        else:           # the same through a pinned plan (cfg + 16 x order), as the tuner sets it
+            L.knob_set("tile_order", 0)
+            c, sp, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            plans = []
+            for mode in (0, 1, 2):      # the plans of the runs above (a forced configuration included)
+                L.check(L.lib.gan_conv_plan_get(mode, gp, ctypes.byref(c), ctypes.byref(sp), ctypes.byref(thin)))
+                plans.append((c.value, sp.value))
+            L.knob_set("force_cfg", -1)
+            for mode, (pc, ps) in enumerate(plans):
+                L.check(L.lib.gan_conv_plan_set(mode, gp, pc % 16 + 16 * (-order), ps))
         y, dx, dw = (torch.full_like(t, float('nan')) for t in (dy, x, wt))
         wp, wn = _ws(L, g)
         st = L.stream()
@@ -585,8 +611,10 @@ def test_xcd_grouped_tile_order_is_a_permutation_of_the_launch_order(L, case, cf
         L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(x), L.ptr(dy), L.ptr(dw), None, 0, wp, wn, st))
         torch.cuda.synchronize()
         outs.append((y, dx, dw))
-    for a, b in zip(*outs):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+    L.lib.gan_conv_plan_clear()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("case,accumulate", [((4, 16, 16, 64, 128, 5, 2), 0), ((2, 12, 12, 3, 16, 5, 2), 1),

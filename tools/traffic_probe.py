@@ -32,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--replays", type=int, default=3)
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--plans", default=None, help="JSON file of tuned plans: written if absent, pinned if present "
+                    "(so that the two counter passes run the same kernels)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     mark = torch.zeros(4, device='cuda')
@@ -42,11 +44,28 @@ def main():
     marker(mark)
     big_b.copy_(big_a)
     small_b.copy_(small_a)
+    # the gather shape of the contraction kernels: a 1x1 convolution reads every input value once, 64 bytes per
+    # pixel and 16-deep slice (for 64 channels: a quarter of each pixel's 256 bytes per slice)
+    import ctypes
+    from gan_amd.ops import _conv_geom
+    for n, hw, cb in ((1024, 32, 64), (2048, 32, 16)):     # 268.4 MB and 134.2 MB of input
+        xg = torch.randn(n, hw, hw, cb, device='cuda')
+        wg = torch.randn(1, 1, cb, 64, device='cuda')
+        yg = torch.empty(n, hw, hw, 64, device='cuda')
+        g = _conv_geom(n, hw, hw, cb, 64, 1, 1, 1, 1, 'SAME')
+        wsb = int(_lib.lib.gan_conv_workspace_bytes(ctypes.byref(g)))
+        wsp, wsn = _lib.workspace(wsb)
+        _lib.check(_lib.lib.gan_conv2d_fwd(ctypes.byref(g), _lib.ptr(xg), _lib.ptr(wg), None, _lib.ptr(yg), wsp, wsn, stream()))
+        torch.cuda.synchronize()
+        print("gather calibration: x %s = %.1f MB read once" % (tuple(xg.shape), xg.numel() * 4 / 1e6), flush=True)
+        del xg, wg, yg
     marker(mark)
     torch.cuda.synchronize()
     del big_a, big_b
 
     autotune.enable(not args.no_autotune)
+    if args.plans and os.path.exists(args.plans):
+        autotune.load(args.plans)
     model = DCGAN(None, bench.dcgan64_opts(seed=0), load_data=False)
     rng = np.random.default_rng(1000)
     im = torch.from_numpy(rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)).cuda()
@@ -54,6 +73,8 @@ def main():
     for _ in range(2):
         model.train_iteration(im, z)
     torch.cuda.synchronize()
+    if args.plans and not os.path.exists(args.plans):
+        autotune.save(args.plans)
     holder = torch.cuda.CUDAGraph()
     with bench.ContractionRecorder(_lib) as rec:
         with torch.cuda.graph(holder):

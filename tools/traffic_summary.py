@@ -57,7 +57,8 @@ def main():
     (wc0, wc1), (wk0, wk1) = regions(wr)
     cal_bytes = [512 * 2 ** 20, 16 * 2 ** 20]
     fcal, wcal = fr[fc0:fc1], wr[wc0:wc1]
-    assert len(fcal) == 2 and len(wcal) == 2, "calibration region should hold the two copies"
+    assert len(fcal) >= 2 and len(wcal) >= 2, "calibration region should start with the two copies"
+    gather_cal = [r for r in fcal[2:] if "igemm" in r["name"]]      # the two 1x1 convolutions
     fetch_factor = cal_bytes[0] / (fcal[0]["c"]["FETCH_SIZE"] * 1024)
     bytes_per_wreq = cal_bytes[0] / wcal[0]["c"]["TCC_WRITE_sum"]
     lines = ["# HBM-side traffic of the contraction family, DCGAN-64 batch 64 (round 2)", "",
@@ -75,6 +76,13 @@ def main():
     lines += ["", "FETCH_SIZE is doubled (the guide's gfx950 correction; the large copy shows x%.3f).  WRITE_SIZE is used as "
               "reported (both copies come out exact, the 16 MiB one as %.1f MiB); TCC_WRITE_sum x %.1f bytes is the "
               "cross-check column." % (fetch_factor, wcal[1]["c"]["WRITE_SIZE"] / 1024, bytes_per_wreq), ""]
+    if gather_cal:
+        lines += ["Gather calibration (1x1 convolution, every input value read once, 64 bytes per pixel and 16-deep slice; "
+                  "268.4 MB of 64-channel input, then 134.2 MB of 16-channel input):", "", "| kernel | FETCH_SIZE reports | x factor |", "|---|---|---|"]
+        for r, expect in zip(gather_cal, (268.435456e6, 134.217728e6)):
+            raw = r["c"]["FETCH_SIZE"] * 1024
+            lines.append("| `%s` grid %d | %.1f MB | %.3f |" % (short(r["name"]), r["grid"], raw / 1e6, expect / raw))
+        lines.append("")
     agg = collections.OrderedDict()
     for r in fr[fk0:fk1]:
         k = short(r["name"])
