@@ -82,6 +82,7 @@ struct IgemmArgs {
     Epilogue epi;  // applied where the final value is stored: here when splits == 1, else by the slab reduction
     int reflect;   // FPROP / WGRAD: taps that fall outside the big image read its mirror image (tf.pad REFLECT
                    // by pt / pl in front of a VALID convolution) instead of zeros
+    int row3_spr;  // > 0: filter-row gather of a 3-channel big image (igemm_split.h, ROW3), slices per filter row
     int grid_mt, grid_nt, grid_z;  // row tiles, column tiles, (parity classes x k splits) of the one-dimensional grid
     int xcd_order;                 // 0: tiles in launch order; 1 / 2: tile_of_workgroup's XCD-aware orders
 };
@@ -771,6 +772,7 @@ struct Plan {
     int splits, kt_per_split;
     int mt, nt;
     long out_elems;
+    int row3;   // slices per filter row of the 3-channel gather the launch uses (0: none)
     int order;  // pinned tile order (1 launch order, 2 by row tile, 3 by k range) or 0: chosen by tile_order()
 };
 
@@ -867,9 +869,17 @@ static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15)
 
 // The split kernel's loaders move 16 / 8 bytes at a time: both gathered channel counts must be multiples
 // of 4 and both operands below 4 GB (a_bytes / b_bytes are 0 beyond that).
+// RGB layers (FPROP / WGRAD over a 3-channel big image) take the split kernel's filter-row gather: slices per
+// filter row, or 0 when the geometry does not qualify (a run of kw * 3 floats must fit two 16-deep slices).
+static int row3_slices(int mode, const gan_conv_geom& g) {
+    if (mode == MODE_TPROP || g.cb != 3 || g.cs % 4 != 0 || g.kw * 3 > 32) return 0;
+    return (g.kw * 3 + 15) / 16;
+}
+
 static bool split_eligible(int mode, const IgemmArgs& a) {
     const gan_conv_geom& g = a.g;
-    const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0) : (g.cb % 4 == 0 && g.cs % 4 == 0);
+    const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0)
+                                         : ((g.cb % 4 == 0 && g.cs % 4 == 0) || row3_slices(mode, g) > 0);
     return ch && a.a_bytes != 0 && a.b_bytes != 0;
 }
 
@@ -892,6 +902,11 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
         pl.out_elems = (long)M * N;
         pl.va = (g.cb % 4 == 0) ? 4 : 1;
         pl.vb = (g.cs % 4 == 0) ? 4 : 1;
+    }
+    const int real_M = M, real_K = K;
+    if (const int spr = row3_slices(mode, g)) {   // plan on the virtual sizes; undone below if the fp32 kernel runs
+        if (mode == MODE_FPROP) K = g.kh * spr * BK;
+        else M = g.kh * spr * BK;
     }
     if (!a_al) pl.va = 1;
     if (!b_al) pl.vb = 1;
@@ -927,6 +942,11 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     // a pinned or forced split configuration on operands that cannot take it (unaligned views, exact mode)
     if (pl.cfg >= kFirstKg2Cfg && !split_ok) pl.cfg -= kFirstKg2Cfg;
     else if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;
+    // the filter-row gather tiles the VIRTUAL gather axis (kh x slices-per-row x 16)
+    pl.row3 = pl.cfg >= kFirstSplitCfg ? row3_slices(mode, g) : 0;
+    M = real_M; K = real_K;
+    if (pl.row3 && mode == MODE_FPROP) K = g.kh * pl.row3 * BK;
+    if (pl.row3 && mode == MODE_WGRAD) M = g.kh * pl.row3 * BK;
     const int bm = kCfg[pl.cfg].bm, bn = kCfg[pl.cfg].bn;
     pl.mt = (M + bm - 1) / bm;
     pl.nt = (N + bn - 1) / bn;
@@ -1021,6 +1041,12 @@ static void launch_split(const IgemmArgs& a, dim3 grid, hipStream_t s) {
     const gan_conv_geom& g = a.g;
     const bool fast = (MODE == MODE_FPROP) ? (g.cb % 16 == 0)
                     : (MODE == MODE_TPROP) ? (g.cs % 16 == 0) : (g.ws % 4 == 0);
+    if constexpr (MODE != MODE_TPROP) {
+        if (a.row3_spr > 0) {
+            hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false, KG, true>), grid, dim3(256 * KG), 0, s, a);
+            return;
+        }
+    }
     if (fast && !knobs().slow_gather)
         hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, true, KG>), grid, dim3(256 * KG), 0, s, a);
     else
@@ -1082,6 +1108,9 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     a.splits = pl.splits;
     a.kt_per_split = pl.kt_per_split;
     a.slab_elems = pl.out_elems;
+    a.row3_spr = pl.row3;
+    if (pl.row3 && mode == MODE_FPROP) a.K = a.g.kh * pl.row3 * BK;
+    if (pl.row3 && mode == MODE_WGRAD) a.M = a.g.kh * pl.row3 * BK;
     if (pl.splits > 1) {
         a.out = static_cast<float*>(ws);
         a.bias = nullptr;
@@ -1143,6 +1172,7 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.splits = 1; r.kt_per_split = 1; r.slab_elems = 0; r.ncls = 1; r.vec_epilogue = 0;
     r.epi = no_epilogue();
     r.reflect = 0;
+    r.row3_spr = 0;
     r.d_cb = make_fastdiv((unsigned)g.cb);
     r.d_cs = make_fastdiv((unsigned)g.cs);
     r.d_kw = make_fastdiv((unsigned)g.kw);

@@ -62,8 +62,15 @@ __device__ __forceinline__ int unpermute(int pos) {
 // output tile, group g on the g-th half of the workgroup's k range with staging buffers of its own, and the
 // second group hands its accumulators to the first through LDS at the end.  A launch then needs half as many
 // split-K slabs (written once, read once by the reduction) for the same number of waves on the chip.
-template <int MODE, int BM, int BN, int WM, int WN, bool FAST, int KG = 1>
+//
+// ROW3 (FPROP / WGRAD of a 3-channel big image: the layers that read or write RGB pixels).  The gather axis
+// (tap, channel) is re-indexed per FILTER ROW: the kw * 3 values one filter row touches are one contiguous run of
+// floats in memory, padded to p.row3_spr slices of 16 (the pad multiplies zeros).  Element e of the run is column
+// x0 + e / 3, channel e % 3, loaded as one dword with its own range check: neither a per-element tap decode nor
+// vector alignment is needed.  FPROP: the virtual K is kh * spr * 16; WGRAD: the virtual M.
+template <int MODE, int BM, int BN, int WM, int WN, bool FAST, int KG = 1, bool ROW3 = false>
 __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p) {
+    static_assert(!ROW3 || (MODE != MODE_TPROP && !FAST), "the filter-row gather serves FPROP and WGRAD, general arithmetic");
     static_assert(WM * WN == 4, "four waves per block");
     static_assert(BM % 64 == 0 && BN % 64 == 0, "tile sides are multiples of 64");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -170,6 +177,16 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     const int b_rc = (btc >> 1) % (BN / 2);
     const int b_kq = ((btc / BN) << 1) | (btc & 1);
 
+    // filter-row gather: the run elements of this thread (FPROP: 4 consecutive ones per slice half; WGRAD: its row pair)
+    const int r3_len = ROW3 ? g.kw * 3 : 0;          // floats of a filter row
+    const int r3_rows = ROW3 ? p.row3_spr * 16 : 1;  // virtual rows (WGRAD) / k (FPROP) per filter row
+    int w_ta = 0, w_e = 0;                           // WGRAD: filter row and run element of the thread's first row
+    if constexpr (ROW3 && MODE == MODE_WGRAD) {
+        const int mv = m0 + 2 * a_rc;
+        w_ta = mv / r3_rows;
+        w_e = mv - w_ta * r3_rows;
+        a_mvalid = a_on && w_ta < g.kh;
+    }
     // thread-constant byte offsets of the fast paths (a per-slice scalar is added to them)
     unsigned a_rb[A_TRANS ? A_PASS : 1], b_rb[B_TRANS ? B_PASS : 1], b_cj[4];
     bool b_nvalid[B_TRANS ? B_PASS : 1];
@@ -207,8 +224,51 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         dst[0] = __uint_as_float(v[0]); dst[1] = __uint_as_float(v[1]);
     };
 
+    auto ld1 = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off, float& dst) {
+        dst = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+    };
+    // byte offset of run element e (column x0 + e / 3, channel e % 3) of image row `rowbase` (in pixels), or out of range
+    auto r3_off = [&](int rowbase, int x0, int e, bool ok) -> unsigned {
+        const int tc = (e * 11) >> 5;      // e / 3 for e < 32
+        int col = x0 + tc;
+        if (p.reflect) col = reflect_at(col, g.wb);
+        ok = ok & (e < r3_len) & ((unsigned)col < (unsigned)g.wb);
+        return ok ? (unsigned)((rowbase + col) * 3 + (e - 3 * tc)) * 4u : kOutOfRange;
+    };
+
     auto load_a = [&](int kt, AReg& a_reg) {
-        if constexpr (A_TRANS && FAST) {
+        if constexpr (ROW3 && MODE == MODE_FPROP) {
+            const int ta = kt / p.row3_spr;
+            const int e0 = (kt - ta * p.row3_spr) * 16 + t_kq * 4;
+            const bool kv = kt * BK < kend;
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                int iy = a_y0[ps] + ta;
+                if (p.reflect) iy = reflect_at(iy, SH);
+                const bool rowok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH);
+                const int rowbase = a_base[ps] + iy * SW;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ld1(rsrc_a, r3_off(rowbase, a_x0[ps], e0 + j, rowok), a_reg[ps][j]);
+            }
+        } else if constexpr (ROW3) {
+            // WGRAD: rows (w_ta, w_e) and (w_ta, w_e + 1) of 4 consecutive pixels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kt * BK + a_kq * 4 + j;
+                const bool kv = (k < kend) & a_mvalid;
+                const unsigned uk = kv ? (unsigned)k : 0u;
+                const int img = fdiv(uk, p.d_hsws);
+                const int rem = uk - img * (int)p.d_hsws.d;
+                const int oy = fdiv(rem, p.d_ws);
+                const int ox = rem - oy * g.ws;
+                int iy = oy * g.sh + w_ta - g.pt;
+                if (p.reflect) iy = reflect_at(iy, g.hb);
+                const bool rowok = kv & ((unsigned)iy < (unsigned)g.hb);
+                const int rowbase = (img * g.hb + iy) * g.wb, x0 = ox * g.sw - g.pl;
+                ld1(rsrc_a, r3_off(rowbase, x0, w_e, rowok), a_reg[j][0]);
+                ld1(rsrc_a, r3_off(rowbase, x0, w_e + 1, rowok), a_reg[j][1]);
+            }
+        } else if constexpr (A_TRANS && FAST) {
             // scalar: the slice's tap and first channel
             const unsigned k0 = (unsigned)__builtin_amdgcn_readfirstlane(kt * BK);
             const int tapc = fdiv(k0, dSC);
@@ -326,6 +386,15 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 const unsigned off = (unsigned)((wtap * g.cb + n) * g.cs + cc) * 4u;
                 ld4(rsrc_b, ok ? off : kOutOfRange, b_reg[ps]);
             }
+        } else if constexpr (ROW3 && MODE == MODE_FPROP) {
+            // virtual k row r of slice kt = run element e of filter row ta: weight row ta * kw * 3 + e, zeros beyond the run
+            const int ta = kt / p.row3_spr;
+            const int eb = (kt - ta * p.row3_spr) * 16;
+            const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((ta * r3_len + eb) * N * 4);
+            const bool kv = kt * BK < kend;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ld2(rsrc_b, (b_pair_valid & kv & (eb + b_kq * 4 + j < r3_len)) ? b_cj[j] + u : kOutOfRange, b_reg[j]);
         } else {
             // row-major [K][N]: a constant of the thread per k row plus the slice's scalar offset
             const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane(kt * BK * N * 4);
@@ -494,6 +563,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 const int y = g.sh * (cl.hq0 + yq) + cl.ph - g.pt;
                 const int x = g.sw * (cl.wq0 + xq) + cl.pw - g.pl;
                 off = ((img * g.hb + y) * g.wb + x) * g.cb;
+            } else if constexpr (ROW3 && MODE == MODE_WGRAD) {
+                const int ta = m / r3_rows, e = m - ta * r3_rows;      // virtual row -> filter row, run element
+                off = e < r3_len ? (ta * r3_len + e) * N : -1;
             } else {
                 off = m * N;
             }
