@@ -43,7 +43,9 @@ class ContractionTimer(object):
     (torch's current stream is the stream the library is given) and tallies nominal FLOPs."""
 
     CONV = ["gan_conv2d_fwd", "gan_conv2d_dgrad", "gan_conv2d_wgrad",
-            "gan_deconv2d_fwd", "gan_deconv2d_dgrad", "gan_deconv2d_wgrad"]
+            "gan_deconv2d_fwd", "gan_deconv2d_dgrad", "gan_deconv2d_wgrad",
+            "gan_conv2d_fwd_act", "gan_deconv2d_fwd_act", "gan_conv2d_dgrad_gated", "gan_deconv2d_dgrad_gated",
+            "gan_conv2d_fwd_reflect", "gan_conv2d_wgrad_reflect"]
     LIN = ["gan_linear_fwd", "gan_linear_dgrad", "gan_linear_wgrad"]
 
     def __init__(self, L):

@@ -940,8 +940,12 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     }
     if (knobs().force_cfg >= 0) pl.cfg = knobs().force_cfg % kNumCfg;
     // a pinned or forced split configuration on operands that cannot take it (unaligned views, exact mode)
-    if (pl.cfg >= kFirstKg2Cfg && !split_ok) pl.cfg -= kFirstKg2Cfg;
-    else if (pl.cfg >= kFirstSplitCfg && !split_ok) pl.cfg -= kFirstSplitCfg;
+    if (pl.cfg >= kFirstKg2Cfg && !split_ok) {
+        pl.cfg -= kFirstKg2Cfg;
+        pinned_splits *= 2;  // a plan tuned for two k groups per workgroup: the one-group kernel wants twice the slabs
+    } else if (pl.cfg >= kFirstSplitCfg && !split_ok) {
+        pl.cfg -= kFirstSplitCfg;
+    }
     // the filter-row gather tiles the VIRTUAL gather axis (kh x slices-per-row x 16)
     pl.row3 = pl.cfg >= kFirstSplitCfg ? row3_slices(mode, g) : 0;
     M = real_M; K = real_K;

@@ -63,6 +63,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--summarise", default=None)
+    ap.add_argument("--cfg", type=int, default=-1, help="force this tile configuration (knob force_cfg)")
+    ap.add_argument("--splits", type=int, default=0, help="force this split-K factor (knob force_splits)")
     args = ap.parse_args()
     if args.summarise:
         return summarise(args.summarise)
@@ -70,6 +72,8 @@ def main():
     from gan_amd import _lib as L
     from gan_amd.ops import _conv_geom
     mark = torch.zeros(4, device='cuda')
+    L.knob_set("force_cfg", args.cfg)
+    L.knob_set("force_splits", args.splits)
     print("| layer pass | " + " | ".join(NAMES[o] for o in ORDERS) + " | chosen |  (us per launch incl. slab reduction)")
     print("|---|" + "---|" * (len(ORDERS) + 1))
     for ln, (n, h, w, cb, cs, k, s) in LAYERS:
