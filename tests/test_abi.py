@@ -85,7 +85,7 @@ def test_plan_pinning_is_host_side_bookkeeping():
     assert L.lib.gan_conv_plan_set(0, gp, 9 + 16, 1) != 0 and L.lib.gan_conv_plan_set(0, gp, 5 + 64, 1) != 0
     L.check(L.lib.gan_conv_plan_set(0, gp, 8, 2))
     L.lib.gan_set_exact_f32(1)
-    assert get(0)[:2] == (1, 2)
+    assert get(0)[:2] == (1, 4)        # two k groups per workgroup fall back to one: twice the slabs
     L.lib.gan_set_exact_f32(0)
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     godd = L.conv_geom(8, 16, 16, 6, 8, 8, 10, 5, 5, 2, 2, 1, 1)
