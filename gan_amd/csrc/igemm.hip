@@ -923,9 +923,14 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
         pl.cfg += kFirstSplitCfg;
         // fewer 128x128 tiles than CUs: the k range is split anyway, so split it inside the workgroup first
         // (two wave groups per tile, half the slabs); the tuner's choices on the DCGAN / CycleGAN shapes agree
+        const long ncls = mode == MODE_TPROP ? a.ncls : 1;
         if (pl.cfg == kFirstSplitCfg) {
-            const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * (mode == MODE_TPROP ? a.ncls : 1);
-            if (tiles < 256 && (K + BK - 1) / BK >= 24) pl.cfg = kFirstKg2Cfg;
+            const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * ncls;
+            if (tiles <= 256 && (K + BK - 1) / BK >= 24) pl.cfg = kFirstKg2Cfg;
+        } else if (pl.cfg == kFirstSplitCfg + 1) {
+            // 128x64 tiles: two workgroups of two k groups fit a CU
+            const long tiles = (long)((M + 127) / 128) * ((N + 63) / 64) * ncls;
+            if (tiles <= 512 && (K + BK - 1) / BK >= 24) pl.cfg = kFirstKg2Cfg + 1;
         }
     }
     int pinned_splits = 0;
