@@ -32,8 +32,10 @@ MAX_SLAB_BYTES = 256 << 20
 MIN_GAIN = 0.03      # a candidate must beat the heuristic by this fraction to replace it
 FINALISTS = 5        # candidates of the quick scan that are timed again
 FINAL_REPS = 12
-ORDER_STRIDE = 16    # plan_set's cfg = tile configuration + 16 * tile order (0: the library's choice)
-ORDER_GAIN = 0.02    # an explicit tile order must beat the library's choice by this fraction
+ORDER_STRIDE = 16    # plan_set's cfg = tile configuration + 16 * tile order (0: the library's choice).  The tuner does
+                     # not time tile orders: a layer pass timed alone, launch after launch, keeps its operands in the
+                     # L2s from one repetition to the next, which favours the XCD-grouped orders by 8-15 % where a
+                     # whole training iteration measures no gain or a loss.
 
 
 def enable(flag=True):
@@ -155,14 +157,6 @@ def tune_geometry(g, reps=3, verbose=False):
                     best = (cfg, splits, us)
             if not (best[:2] != heur and best[2] < base * (1.0 - MIN_GAIN)):
                 best = (heur[0], heur[1], base)
-            # stage 3: the tile order (which tiles share an XCD's L2) of the chosen plan.  Fewer bytes over the
-            # fabric are not always less time, so the clock decides; the library's choice stays unless beaten.
-            tile_cfg, splits = best[0] % ORDER_STRIDE, best[1]
-            for order in (1, 2, 3):
-                check(lib.gan_conv_plan_set(mode, gp, tile_cfg + ORDER_STRIDE * order, splits))
-                us = min(_time(run, FINAL_REPS), _time(run, FINAL_REPS))
-                if us < best[2] * (1.0 - ORDER_GAIN):
-                    best = (tile_cfg + ORDER_STRIDE * order, splits, us)
             if best[:2] != heur:
                 check(lib.gan_conv_plan_set(mode, gp, best[0], best[1]))
             else:

@@ -84,7 +84,7 @@ struct IgemmArgs {
                    // by pt / pl in front of a VALID convolution) instead of zeros
     int row3_spr;  // > 0: filter-row gather of a 3-channel big image (igemm_split.h, ROW3), slices per filter row
     int grid_mt, grid_nt, grid_z;  // row tiles, column tiles, (parity classes x k splits) of the one-dimensional grid
-    int xcd_order;                 // 0: tiles in launch order; 1 / 2: tile_of_workgroup's XCD-aware orders
+    int xcd_order;                 // tile_of_workgroup: 0 / 3 launch order (k range / row tile fastest), 1 / 2 XCD-aware
 };
 
 // Which tile a workgroup computes.  The grid is one-dimensional.  The hardware hands workgroups to the 8 XCDs
@@ -98,13 +98,14 @@ struct IgemmArgs {
 //   order 2 (by k range)   all row and column tiles of one (class, k split) are neighbours.  WGRAD: a k split is a
 //                  range of images, which every filter tap reads, shifted.  FPROP / TPROP: a k split is a range of
 //                  filter taps, read by every row tile, so a large filter crosses the fabric once.
+// Orders 0 and 3 are plain launch orders (no XCD grouping) with the k range resp. the row tile fastest.
 struct TileId { int mt, nt, z; };
 template <int MODE>
 __device__ __forceinline__ TileId tile_of_workgroup(const IgemmArgs& p) {
     const unsigned MT = (unsigned)p.grid_mt, NT = (unsigned)p.grid_nt, Z = (unsigned)p.grid_z;
     const unsigned L = blockIdx.x;
     unsigned w = L;
-    if (p.xcd_order) {
+    if (p.xcd_order == 1 || p.xcd_order == 2) {
         const unsigned T = MT * NT * Z;
         const unsigned per = (T + 7u) >> 3;                  // work items of a "tall" XCD
         const unsigned tall = (T & 7u) ? (T & 7u) : 8u;      // XCDs that receive `per` items (the rest per - 1)
@@ -112,7 +113,7 @@ __device__ __forceinline__ TileId tile_of_workgroup(const IgemmArgs& p) {
         w = xcd < tall ? xcd * per + loc : tall * per + (xcd - tall) * (per - 1u) + loc;
     }
     TileId t;
-    if (MODE == MODE_WGRAD || p.xcd_order == 2) {
+    if (MODE == MODE_WGRAD || p.xcd_order >= 2) {     // 3: row tile fastest in plain launch order
         t.mt = (int)(w % MT);
         const unsigned r = w / MT;
         t.nt = (int)(r % NT);
@@ -1080,15 +1081,22 @@ static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
 // Which XCD-aware tile order a launch uses (tile_of_workgroup).  FPROP / TPROP: by row tile, the image operand
 // crosses the fabric about once and the filter once per XCD (8 times); by k range it is the other way round.
 static int tile_order(int mode, const IgemmArgs& a, const Plan& pl) {
-    const int k = knobs().tile_order > 0 ? knobs().tile_order : pl.order;
-    if (k == 1) return 0;             // plain launch order
-    if (k == 2 || k == 3) return k - 1;
+    int k = knobs().tile_order > 0 ? knobs().tile_order : pl.order;
+    if (k >= 1000) {   // test knob: one decimal digit per mode, 1FTW (FPROP, TPROP, WGRAD), 0 = chosen here
+        k -= 1000;
+        k = mode == MODE_FPROP ? k / 100 : (mode == MODE_TPROP ? (k / 10) % 10 : k % 10);
+        if (k == 0) k = pl.order;
+    }
+    if (k >= 1 && k <= 4) return k - 1;
+    // Chosen by what a whole training iteration measures, not by a layer pass timed alone (there, launch after
+    // launch with warm L2s, the XCD grouping looks 8-15 % better for the transposed contraction than it is):
+    //   WGRAD  by k range: same time as any other order, a fifth of the fabric bytes;
+    //   TPROP  row tile fastest in launch order: grouping its parity classes on one XCD costs 3 % of a DCGAN step;
+    //   FPROP  by row tile or by k range, whichever moves fewer bytes (same time as launch order).
     if (mode == MODE_WGRAD) return 2;
-    // a strided transposed contraction runs its parity classes as separate tiles, which gather the same pixels:
-    // measured 8-15 % faster with the classes of a row tile side by side, whatever the filter size
-    if (mode == MODE_TPROP && a.ncls > 1) return 1;
+    if (mode == MODE_TPROP) return 3;
     const gan_conv_geom& g = a.g;
-    const double image = (mode == MODE_FPROP) ? 4.0 * g.n * g.hb * g.wb * g.cb : 4.0 * g.n * g.hs * g.ws * g.cs;
+    const double image = 4.0 * g.n * g.hb * g.wb * g.cb;
     const double filter = 4.0 * g.kh * g.kw * g.cb * g.cs;
     return image + 8.0 * filter <= 8.0 * image + filter ? 1 : 2;
 }

@@ -229,8 +229,9 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
  * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
  * cfg may carry a tile order as well, cfg = tile configuration + 16 * order: which output tile a workgroup
  * computes as a function of its launch position (workgroups go to the 8 XCDs round robin, each XCD has its own
- * L2): 0 chosen by the library, 1 launch order, 2 all k splits / parity classes / column tiles of a row tile side
- * by side on one XCD, 3 all tiles of one k range side by side.  Results do not depend on it.
+ * L2): 0 chosen by the library, 1 launch order with the k range fastest, 2 all k splits / parity classes / column
+ * tiles of a row tile side by side on one XCD, 3 all tiles of one k range side by side, 4 launch order with the row
+ * tile fastest.  Results do not depend on it.
  * gan_conv_plan_get reports the plan in effect (cfg in the same encoding) (`thin` = 1 when mode 1 takes the vector-ALU path
  * for outputs of <= 4 channels, which has no plan).  Changing a plan changes the workspace size
  * gan_conv_workspace_bytes reports.  gan_linear_as_conv_geom yields the geometry under which
@@ -263,10 +264,11 @@ int gan_get_exact_f32(void);
  *   "three_launch_bn" GAN_HIP_THREE_LAUNCH_BN=1  small batch norms (<= 1024 rows per group) on the general path
  *   "separate_colsum" GAN_HIP_SEPARATE_COLSUM=1  bias gradients as two launches after the weight gradient
  *                                                (bit-identical to the default, fused placement)
- *   "tile_order"      GAN_HIP_TILE_ORDER=<0..3>  which tile a contraction workgroup computes: 0 chosen per launch so
- *                                                that tiles sharing operand bytes run on one XCD, 1 plain launch
- *                                                order, 2 grouped by row tile, 3 grouped by k range (bit-identical
- *                                                results; for traffic measurements)
+ *   "tile_order"      GAN_HIP_TILE_ORDER=<0..4>  which tile a contraction workgroup computes: 0 chosen per launch,
+ *                                                1 launch order with the k range fastest, 2 grouped by row tile so
+ *                                                that tiles sharing operand bytes run on one XCD, 3 grouped by k
+ *                                                range, 4 launch order with the row tile fastest; 1000 + three
+ *                                                digits sets it per mode (bit-identical results; for measurements)
  * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe
  * against concurrent calls into the library. */
 int gan_knob_set(const char* name, int value);

@@ -82,7 +82,7 @@ def test_plan_pinning_is_host_side_bookkeeping():
     # cfg may carry a tile order (16 x order, 1..3); it is reported back in the same encoding
     L.check(L.lib.gan_conv_plan_set(0, gp, 8 + 16 * 2, 2))
     assert get(0)[:2] == (8 + 32, 2)
-    assert L.lib.gan_conv_plan_set(0, gp, 9 + 16, 1) != 0 and L.lib.gan_conv_plan_set(0, gp, 5 + 64, 1) != 0
+    assert L.lib.gan_conv_plan_set(0, gp, 9 + 16, 1) != 0 and L.lib.gan_conv_plan_set(0, gp, 5 + 80, 1) != 0
     L.check(L.lib.gan_conv_plan_set(0, gp, 8, 2))
     L.lib.gan_set_exact_f32(1)
     assert get(0)[:2] == (1, 4)        # two k groups per workgroup fall back to one: twice the slabs

@@ -613,7 +613,7 @@ def test_xcd_grouped_tile_order_is_a_permutation_of_the_launch_order(L, case, cf
         L.knob_set("force_cfg", cfg)
     L.knob_set("no_thin", 1)
     outs = []
-    for order in (1, 0, 2, 3, -2):
+    for order in (1, 0, 2, 3, 4, 1234, -2):
         if order >= 0:
             L.knob_set("tile_order", order)
         else:           # the same through a pinned plan (cfg + 16 x order), as the tuner sets it
