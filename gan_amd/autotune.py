@@ -72,7 +72,10 @@ def _candidates(mode, g):
     m, n, k, out = _problem(mode, g)
     nkt = (k + 15) // 16
     cands = []
-    split_ok = not lib.gan_get_exact_f32() and g.cs % 4 == 0 and (mode == 1 or g.cb % 4 == 0 or (g.cb == 3 and g.kw <= 10))
+    # the library knows which geometries its bf16 kernels take: it refuses to pin one of their configurations otherwise
+    gp = ctypes.byref(g)
+    split_ok = not lib.gan_get_exact_f32() and lib.gan_conv_plan_set(mode, gp, FIRST_SPLIT_CFG, 1) == 0
+    check(lib.gan_conv_plan_set(mode, gp, -1, 1))
     for cfg, (bm, bn) in enumerate(TILE):
         if bn >= 4 * n and bn > 32:
             continue                                  # tile mostly padding in N

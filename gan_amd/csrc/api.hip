@@ -65,6 +65,7 @@ Knobs& knobs() {
         r.three_launch_bn = getenv("GAN_HIP_THREE_LAUNCH_BN") != nullptr;
         r.separate_colsum = getenv("GAN_HIP_SEPARATE_COLSUM") != nullptr;
         r.tile_order = env_int("GAN_HIP_TILE_ORDER", 0);
+        r.rgb_gather = env_int("GAN_HIP_RGB_GATHER", 1);
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
         return r;
     }();
@@ -487,6 +488,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "three_launch_bn")) k.three_launch_bn = value != 0;
     else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
     else if (!strcmp(name, "tile_order")) k.tile_order = value;
+    else if (!strcmp(name, "rgb_gather")) k.rgb_gather = value;
     else return fail("gan_knob_set: unknown knob '%s'", name);
     return 0;
 }

@@ -35,6 +35,7 @@ struct Knobs {
     int scalar_epilogue;  // GAN_HIP_SCALAR_EPILOGUE: dword stores instead of the 16-byte epilogue
     int three_launch_bn;  // GAN_HIP_THREE_LAUNCH_BN: small batch norms on the general path
     int separate_colsum;  // GAN_HIP_SEPARATE_COLSUM: bias gradients as launches of their own
+    int rgb_gather;       // GAN_HIP_RGB_GATHER: filter-row gather for 3-channel images: 1 FPROP and WGRAD, 2 WGRAD only, 0 off
     int tile_order;       // GAN_HIP_TILE_ORDER: 0 chosen per launch, 1 launch order, 2 by row tile, 3 by k range
     int exact_f32;      // GAN_HIP_EXACT_F32: default of gan_set_exact_f32
 };

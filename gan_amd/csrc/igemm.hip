@@ -874,6 +874,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15)
 // filter row, or 0 when the geometry does not qualify (a run of kw * 3 floats must fit two 16-deep slices).
 static int row3_slices(int mode, const gan_conv_geom& g) {
     if (mode == MODE_TPROP || g.cb != 3 || g.cs % 4 != 0 || g.kw * 3 > 32) return 0;
+    if (knobs().rgb_gather == 0 || (knobs().rgb_gather == 2 && mode == MODE_FPROP)) return 0;
     return (g.kw * 3 + 15) / 16;
 }
 

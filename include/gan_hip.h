@@ -269,6 +269,9 @@ int gan_get_exact_f32(void);
  *                                                that tiles sharing operand bytes run on one XCD, 3 grouped by k
  *                                                range, 4 launch order with the row tile fastest; 1000 + three
  *                                                digits sets it per mode (bit-identical results; for measurements)
+ *   "rgb_gather"      GAN_HIP_RGB_GATHER=<0..2>  filter-row gather of the bf16 kernels for 3-channel images: 1 (default)
+ *                                                forward and weight gradient, 2 weight gradient only, 0 off (those
+ *                                                layers then run on the fp32 MFMA kernel)
  * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe
  * against concurrent calls into the library. */
 int gan_knob_set(const char* name, int value);
