@@ -198,7 +198,7 @@ def exact_f32_step_ms(model, pool, _lib, steps=10):
     try:
         ops._ws_cache.clear()
         model.train_iteration(*pool[0])
-        run = model.iteration_runner(pool[0][0], pool[0][1])
+        run = model.iteration_runner(pool[0][0], pool[0][1], segmented=False if args.dp_whole_graph else None)
         for i in range(3):
             run(*pool[i % len(pool)])
         torch.cuda.synchronize()
@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--dp-whole-graph", action="store_true",
+                    help="data parallel: capture the all-reduces INTO one HIP graph instead of cutting the iteration "
+                         "into a chain of graphs around them (RCCL under graph capture: not yet run with more than one rank)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="one GPU only: run the data-parallel path (segmented graphs + RCCL all-reduce) on a one-rank group")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -331,7 +334,7 @@ def main():
     if args.no_graph:
         run = lambda im, z, y=None: model.train_iteration(im, z, y)
     else:
-        run = model.iteration_runner(pool[0][0], pool[0][1])
+        run = model.iteration_runner(pool[0][0], pool[0][1], segmented=False if args.dp_whole_graph else None)
 
     def barrier():
         if dist is not None:
@@ -409,6 +412,7 @@ def main():
                                    "1 D update + 2 G updates per step (models/dcgan.py:262-275)",
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 and pg is None
+                                                               else "one hipGraph holding the %s all-reduces" % args.backend if args.dp_whole_graph
                                                                else "hipGraph segments + %s all-reduce overlapped with the backward pass"
                                                                % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")),
                        "schedule": "the first G update reuses the D update's generator pass (same z, same weights; "
