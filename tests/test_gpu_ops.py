@@ -158,6 +158,23 @@ def test_conv2d_rgb_layers(L, case):
     _conv_case(L, case, 8, 2)
 
 
+# thin OUTPUT of a stride-1 forward pass (<= 4 output channels: CycleGAN's 7x7 head 64 -> 3, the discriminators'
+# prediction layer 512 -> 1); these stay on the 128x32 MFMA tile
+THIN_FWD_CONVS = [
+    (1, 20, 18, 32, 3, 7, 1, 'VALID'),
+    (2, 16, 16, 16, 1, 4, 1, 'SAME'),
+    (1, 40, 70, 64, 3, 7, 1, 'SAME'),
+    (2, 9, 11, 48, 4, 3, 1, 'SAME'),
+    (3, 8, 8, 512, 1, 4, 1, 'SAME'),
+    (1, 33, 5, 16, 2, 5, 1, 'SAME'),
+]
+
+
+@pytest.mark.parametrize("case", THIN_FWD_CONVS)
+def test_conv2d_thin_output_shapes(L, case):
+    _conv_case(L, case)
+
+
 # n, hs, ws, cs(in), cb(out), k, s, out_h, out_w   (deconv2d: x [n,hs,ws,cs] -> y [n,oh,ow,cb])
 SMALL_DECONVS = [
     (2, 4, 4, 8, 4, 5, 2, 8, 8),
