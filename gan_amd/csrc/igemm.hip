@@ -705,9 +705,12 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
     const int i0 = cl.hq0 + qh_t - (khc - 1), j0 = cl.wq0 + qw_t - (kwc - 1);
     const int lqh = threadIdx.x >> 5, lqw = threadIdx.x & 31;
     const float* in_img = p.in + (long)img * g.hs * g.ws * g.cs;
-    float acc[CB];
+    // accumulators in pairs (even k, odd k): the inner product runs on the packed fp32 FMA, two channels of the
+    // chunk per instruction, with the filter pair as a scalar-register operand
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[CB];
 #pragma unroll
-    for (int c = 0; c < CB; ++c) acc[c] = 0.f;
+    for (int c = 0; c < CB; ++c) acc2[c] = f32x2{0.f, 0.f};
 
     for (int c0 = 0; c0 < g.cs; c0 += kThinCC) {
         __syncthreads();
@@ -727,21 +730,26 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
         for (int ta = 0; ta < khc; ++ta)
             for (int tb = 0; tb < kwc; ++tb) {
                 const float* xp = &tile[((lqh + khc - 1 - ta) * RW + (lqw + kwc - 1 - tb)) * kThinPix];
-                float x[kThinCC];
+                f32x2 x[kThinCC / 2];
 #pragma unroll
                 for (int k = 0; k < kThinCC; k += 4) {
                     const float4 v = *reinterpret_cast<const float4*>(xp + k);
-                    x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
+                    x[k / 2] = f32x2{v.x, v.y};
+                    x[k / 2 + 1] = f32x2{v.z, v.w};
                 }
                 // uniform address: tap (cl.ph + sh*ta, cl.pw + sw*tb), channels c0..c0+15
                 const float* wp = p.w + ((long)((cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb)) * g.cb) * g.cs + c0;
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
+                    const f32x2* wq = reinterpret_cast<const f32x2*>(wp + (long)c * g.cs);   // cs and c0 are multiples of 16
 #pragma unroll
-                    for (int k = 0; k < kThinCC; ++k) acc[c] = fmaf(x[k], wp[(long)c * g.cs + k], acc[c]);
+                    for (int k = 0; k < kThinCC / 2; ++k) acc2[c] = __builtin_elementwise_fma(x[k], wq[k], acc2[c]);
                 }
             }
     }
+    float acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = acc2[c].x + acc2[c].y;
     const int qh = qh_t + lqh, qw = qw_t + lqw;
     if (qh < cl.hq && qw < cl.wq) {
         const int h = (cl.hq0 + qh) * g.sh + cl.ph - g.pt, w = (cl.wq0 + qw) * g.sw + cl.pw - g.pl;
