@@ -198,7 +198,7 @@ def exact_f32_step_ms(model, pool, _lib, steps=10):
     try:
         ops._ws_cache.clear()
         model.train_iteration(*pool[0])
-        run = model.iteration_runner(pool[0][0], pool[0][1], segmented=False if args.dp_whole_graph else None)
+        run = model.iteration_runner(pool[0][0], pool[0][1])
         for i in range(3):
             run(*pool[i % len(pool)])
         torch.cuda.synchronize()
