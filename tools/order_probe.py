@@ -7,7 +7,9 @@ events, or -- under `rocprofv3 --pmc FETCH_SIZE --output-format csv` -- L2-to-fa
     python tools/order_probe.py --summarise out       # read MB per launch from the counter pass
 
 Every (layer, pass, order) group of launches is preceded by one 3-element gan_fill launch, which the summary uses
-as a separator."""
+as a separator.  NOTE: a layer pass timed alone, launch after launch, keeps its operands in the L2s between repetitions,
+which flatters the XCD-grouped orders; the library's choice was made on whole-iteration timings (bench.py with the
+tile_order knob)."""
 import argparse
 import csv
 import ctypes
@@ -22,8 +24,8 @@ LAYERS = [("d_h1", (64, 32, 32, 64, 128, 5, 2)), ("d_h2", (64, 16, 16, 128, 256,
           ("d_h1x2", (128, 32, 32, 64, 128, 5, 2)), ("d_h2x2", (128, 16, 16, 128, 256, 5, 2)), ("d_h3x2", (128, 8, 8, 256, 512, 5, 2)),
           ("res3x3", (1, 64, 64, 256, 256, 3, 1)), ("cyc_d2", (1, 64, 64, 128, 256, 4, 2))]
 PASSES = ("fwd", "dgrad", "wgrad")
-ORDERS = (1, 2, 3)
-NAMES = {1: "launch order", 2: "by row tile", 3: "by k range"}
+ORDERS = (1, 2, 3, 4)
+NAMES = {1: "launch order, k range fastest", 2: "by row tile (XCD)", 3: "by k range (XCD)", 4: "launch order, row tile fastest"}
 
 
 def groups():
@@ -110,7 +112,7 @@ def main():
             # the order the library takes by itself (its estimate, restated)
             image = 4.0 * n * (h * w * cb if ps == "fwd" else g.hs * g.ws * cs)
             filt = 4.0 * k * k * cb * cs
-            chosen = 3 if ps == "wgrad" else (2 if image + 8 * filt <= 8 * image + filt else 3)
+            chosen = 3 if ps == "wgrad" else (4 if ps == "dgrad" else (2 if image + 8 * filt <= 8 * image + filt else 3))
             print("| %s %s | %s | %s |" % (ln, ps, " | ".join("%.1f" % c for c in cells), NAMES[chosen]), flush=True)
         L.knob_set("tile_order", 0)
 
