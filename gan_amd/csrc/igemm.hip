@@ -676,7 +676,10 @@ struct ThinArgs {
 
 // MAXT bounds the taps per axis of any class and sizes the LDS halo (3: 5x5 stride 2 -> 27 KB, five
 // blocks per CU; 7: up to 7x7 stride 1 -> 42.5 KB).
-template <int CB, int MAXT>
+// TAIL: any channel count and alignment of the small image (the y-conditioned MNIST generator's last layer reads
+// 138 channels): the halo is staged dword by dword with zeros beyond the last channel, and the filter values of a
+// chunk are fetched one by one with the channel index range-checked, so nothing is read beyond a filter row.
+template <int CB, int MAXT, bool TAIL>
 __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
     __shared__ __attribute__((aligned(16))) float tile[(kThinQH + MAXT - 1) * (kThinQW + MAXT - 1) * kThinPix];
     const gan_conv_geom& g = p.g;
@@ -722,8 +725,18 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
             while (cc >= RW) { cc -= RW; ++r; }
             const int i = i0 + r, j = j0 + cc;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i >= 0 && i < g.hs && j >= 0 && j < g.ws)
-                v = *reinterpret_cast<const float4*>(in_img + ((long)i * g.ws + j) * g.cs + c0 + c4 * 4);
+            if (i >= 0 && i < g.hs && j >= 0 && j < g.ws) {
+                const float* src = in_img + ((long)i * g.ws + j) * g.cs + c0 + c4 * 4;
+                if constexpr (!TAIL) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    const int left = g.cs - (c0 + c4 * 4);   // channels from this thread's first one to the last
+                    if (left > 0) v.x = src[0];
+                    if (left > 1) v.y = src[1];
+                    if (left > 2) v.z = src[2];
+                    if (left > 3) v.w = src[3];
+                }
+            }
             *reinterpret_cast<float4*>(&tile[pix * kThinPix + c4 * 4]) = v;
         }
         __syncthreads();
@@ -741,9 +754,20 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
                 const float* wp = p.w + ((long)((cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb)) * g.cb) * g.cs + c0;
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
-                    const f32x2* wq = reinterpret_cast<const f32x2*>(wp + (long)c * g.cs);   // cs and c0 are multiples of 16
+                    if constexpr (!TAIL) {
+                        const f32x2* wq = reinterpret_cast<const f32x2*>(wp + (long)c * g.cs);   // cs and c0 are multiples of 16
 #pragma unroll
-                    for (int k = 0; k < kThinCC / 2; ++k) acc2[c] = __builtin_elementwise_fma(x[k], wq[k], acc2[c]);
+                        for (int k = 0; k < kThinCC / 2; ++k) acc2[c] = __builtin_elementwise_fma(x[k], wq[k], acc2[c]);
+                    } else {
+                        const float* wr = wp + (long)c * g.cs;
+                        const int left = g.cs - c0;   // uniform: channels of this chunk that exist
+#pragma unroll
+                        for (int k = 0; k < kThinCC / 2; ++k) {
+                            const float w0 = 2 * k < left ? wr[2 * k] : 0.f;
+                            const float w1 = 2 * k + 1 < left ? wr[2 * k + 1] : 0.f;
+                            acc2[c] = __builtin_elementwise_fma(x[k], f32x2{w0, w1}, acc2[c]);
+                        }
+                    }
                 }
             }
     }
@@ -1000,8 +1024,8 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
 // the MFMA path.
 static bool thin_tprop_ok(const IgemmArgs& a) {
     const gan_conv_geom& g = a.g;
-    if (g.cb > 4 || g.cs % kThinCC != 0 || a.accumulate) return false;
-    if (!aligned16(a.a) || knobs().force_cfg >= 0 || knobs().no_thin) return false;
+    if (g.cb > 4 || a.accumulate) return false;
+    if (knobs().force_cfg >= 0 || knobs().no_thin) return false;
     for (int i = 0; i < a.ncls; ++i)
         if (a.cls[i].khc > kThinMaxTaps || a.cls[i].kwc > kThinMaxTaps) return false;
     return true;
@@ -1028,9 +1052,14 @@ static int run_thin_tprop(const IgemmArgs& a, hipStream_t s, const char* what) {
         if (a.cls[i].khc > maxt) maxt = a.cls[i].khc;
         if (a.cls[i].kwc > maxt) maxt = a.cls[i].kwc;
     }
-#define GAN_THIN_LAUNCH(CBV)                                                                            \
-    if (maxt <= 3) hipLaunchKernelGGL((tprop_thin_kernel<CBV, 3>), grid, dim3(256), 0, s, t);           \
-    else hipLaunchKernelGGL((tprop_thin_kernel<CBV, kThinMaxTaps>), grid, dim3(256), 0, s, t)
+    // channel counts that are not multiples of the chunk, or an unaligned image, take the dword-by-dword variant
+    const bool tail = (a.g.cs % kThinCC != 0) || !aligned16(a.a) || !aligned16(a.b);
+#define GAN_THIN_LAUNCH(CBV)                                                                                      \
+    if (tail) {                                                                                                   \
+        if (maxt <= 3) hipLaunchKernelGGL((tprop_thin_kernel<CBV, 3, true>), grid, dim3(256), 0, s, t);           \
+        else hipLaunchKernelGGL((tprop_thin_kernel<CBV, kThinMaxTaps, true>), grid, dim3(256), 0, s, t);          \
+    } else if (maxt <= 3) hipLaunchKernelGGL((tprop_thin_kernel<CBV, 3, false>), grid, dim3(256), 0, s, t);       \
+    else hipLaunchKernelGGL((tprop_thin_kernel<CBV, kThinMaxTaps, false>), grid, dim3(256), 0, s, t)
     switch (a.g.cb) {
         case 1: GAN_THIN_LAUNCH(1); break;
         case 2: GAN_THIN_LAUNCH(2); break;

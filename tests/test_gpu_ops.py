@@ -43,6 +43,10 @@ SMALL_CONVS = [
     (3, 28, 28, 1, 16, 5, 2, 'SAME'),
     (2, 12, 12, 4, 16, 3, 2, 'SAME'),
     (2, 70, 41, 3, 48, 5, 2, 'SAME'),      # several 8x32 patches per class, ragged edges
+    # thin big side, cs NOT a multiple of 16: the same path, halo staged dword by dword, filter chunk range-checked
+    (3, 28, 28, 1, 138, 5, 2, 'SAME'),     # MNIST g_h3 (y-conditioned: 128 + 10 channels -> the image)
+    (2, 9, 13, 2, 10, 5, 2, 'SAME'),       # fewer channels than one chunk
+    (1, 33, 20, 4, 37, 3, 1, 'SAME'),      # odd channel count, stride 1
     # thin big side with >= 4096 small-side pixels: the vector-ALU weight-gradient path
     (2, 96, 100, 3, 64, 5, 2, 'SAME'),
     (1, 70, 74, 3, 24, 7, 1, 'VALID'),     # 7x7 stem, cs not a multiple of 64
