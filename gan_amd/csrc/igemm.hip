@@ -912,8 +912,11 @@ static int row3_slices(int mode, const gan_conv_geom& g) {
 
 static bool split_eligible(int mode, const IgemmArgs& a) {
     const gan_conv_geom& g = a.g;
+    // FPROP / WGRAD gather the small side and the filter's cs axis as PAIRS of adjacent channels (8-byte loads), so an
+    // even cs is enough there (138 = 128 + 10 label channels of the y-conditioned MNIST generator); the results then
+    // leave through the dword epilogue.  The big side is read 16 bytes (FPROP) or 8 bytes (WGRAD) at a time.
     const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0)
-                                         : ((g.cb % 4 == 0 && g.cs % 4 == 0) || row3_slices(mode, g) > 0);
+                                         : ((g.cb % 4 == 0 && g.cs % 2 == 0) || row3_slices(mode, g) > 0);
     return ch && a.a_bytes != 0 && a.b_bytes != 0;
 }
 

@@ -37,6 +37,9 @@ SMALL_CONVS = [
     (1, 22, 22, 3, 8, 7, 1, 'VALID'),
     (1, 16, 16, 12, 1, 5, 1, 'SAME'),      # cyclegan d_h3_pred: Cout = 1
     (2, 9, 13, 8, 12, 5, 2, 'SAME'),       # non-square, odd
+    (2, 14, 14, 128, 138, 5, 2, 'SAME'),   # MNIST g_h2 (cs even, not a multiple of 4: pair loads, dword epilogue)
+    (2, 9, 13, 8, 10, 5, 2, 'SAME'),
+    (1, 12, 12, 4, 6, 3, 2, 'SAME'),
     # thin big side (cb <= 4) with cs a multiple of 16: the vector-ALU input-gradient path
     (1, 22, 22, 3, 16, 7, 1, 'VALID'),
     (2, 9, 13, 2, 32, 5, 2, 'SAME'),
