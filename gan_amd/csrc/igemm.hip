@@ -651,6 +651,35 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
     }
 }
 
+// The same for outputs whose element count is not a multiple of 4 (a slab then starts at any dword: no 16-byte
+// loads): a block covers 16 consecutive elements x 16 split lanes.
+__global__ __launch_bounds__(256) void reduce_slabs_wide_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                       const float* __restrict__ bias, long elems, int c,
+                                                                       int splits, int accumulate, int own_blocks,
+                                                                       const ColsumFinal tail, const Epilogue epi) {
+    __shared__ float red[16][17];
+    if ((int)blockIdx.x >= own_blocks) {
+        colsum_final_block(tail, blockIdx.x - own_blocks);
+        return;
+    }
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + col;
+    float s = 0.f;
+    if (i < elems) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += 16) s += slabs[(long)k * elems + i];
+    }
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && i < elems) {
+        for (int j = 1; j < 16; ++j) s += red[j][col];
+        if (bias) s += bias[(int)(i % c)];
+        if (accumulate) s += out[i];
+        if (epi_active(epi)) s = epi_apply(epi, s, i);
+        out[i] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // TPROP with a thin output (cb <= 4: the image-producing deconv of a generator, the input
 // gradient of a discriminator's first conv).  A 32-wide MFMA tile would be >= 87 % padding in N,
@@ -1195,6 +1224,13 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         const int own = (int)((n4 + 15) / 16);
         hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)(own + job.blocks)), dim3(256), 0, s,
                            static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, own, job, a.epi);
+        if (int rc = check_launch(what)) return rc;
+        if (job.blocks > 0) *tail_done = 1;
+    } else if (pl.splits >= 16) {
+        const int own = (int)((pl.out_elems + 15) / 16);
+        hipLaunchKernelGGL(reduce_slabs_wide_scalar_kernel, dim3((unsigned)(own + job.blocks)), dim3(256), 0, s,
+                           static_cast<const float*>(ws), final_out, bias, pl.out_elems, out_c, pl.splits, accumulate, own, job,
+                           a.epi);
         if (int rc = check_launch(what)) return rc;
         if (job.blocks > 0) *tail_done = 1;
     } else if (pl.splits > 1) {

@@ -114,6 +114,15 @@ def test_conv2d_every_tile_config_and_split(L, cfg, splits):
     _conv_case(L, (2, 9, 9, 5, 7, 3, 1, 'SAME'), cfg, splits)      # odd channels: 4..6 fall back to 0..2
 
 
+@pytest.mark.parametrize("case,cfg,splits", [((3, 28, 28, 1, 138, 5, 2, 'SAME'), 2, 20),     # dw: 3450 elements
+                                             ((3, 28, 28, 11, 11, 5, 2, 'SAME'), 3, 16),    # dw: 3025, dx: 25872
+                                             ((2, 14, 14, 128, 138, 5, 2, 'SAME'), 5, 24)])
+def test_many_splits_over_outputs_that_are_no_multiple_of_four(L, case, cfg, splits):
+    """16 or more split-K slabs are summed by split lanes working side by side; when the output's element count is not
+    a multiple of 4 (a slab then starts at any dword) that reduction runs dword by dword."""
+    _conv_case(L, case, cfg, splits)
+
+
 # channel counts that are multiples of 4 (the split-bf16 kernels' condition) with ragged tiles:
 # rows, columns and depth that are not multiples of the tile sides / of the 16-deep slice
 SPLIT_CONVS = [
