@@ -790,11 +790,17 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
                     } else {
                         const float* wr = wp + (long)c * g.cs;
                         const int left = g.cs - c0;   // uniform: channels of this chunk that exist
+                        if (left >= kThinCC) {        // a whole chunk: 16 consecutive dwords, at any dword address
 #pragma unroll
-                        for (int k = 0; k < kThinCC / 2; ++k) {
-                            const float w0 = 2 * k < left ? wr[2 * k] : 0.f;
-                            const float w1 = 2 * k + 1 < left ? wr[2 * k + 1] : 0.f;
-                            acc2[c] = __builtin_elementwise_fma(x[k], f32x2{w0, w1}, acc2[c]);
+                            for (int k = 0; k < kThinCC / 2; ++k)
+                                acc2[c] = __builtin_elementwise_fma(x[k], f32x2{wr[2 * k], wr[2 * k + 1]}, acc2[c]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < kThinCC / 2; ++k) {
+                                const float w0 = 2 * k < left ? wr[2 * k] : 0.f;
+                                const float w1 = 2 * k + 1 < left ? wr[2 * k + 1] : 0.f;
+                                acc2[c] = __builtin_elementwise_fma(x[k], f32x2{w0, w1}, acc2[c]);
+                            }
                         }
                     }
                 }
