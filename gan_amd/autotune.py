@@ -26,7 +26,8 @@ _listeners = []     # callables run after plans changed (workspace size caches)
 MODES = (0, 1, 2)
 SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96, 128, 192, 256)
 TILE = ((128, 128), (128, 64), (64, 64), (128, 32), (128, 128), (128, 64), (64, 64),    # 4..6: split-bf16 MFMA
-        (128, 128), (128, 64))                                                            # 7..8: + two k groups per tile
+        (128, 128), (128, 64),                                                            # 7..8: + two k groups per tile
+        (128, 32))                                                                        # 9: split-bf16, thin outputs
 FIRST_SPLIT_CFG = 4
 MAX_SLAB_BYTES = 256 << 20
 MIN_GAIN = 0.03      # a candidate must beat the heuristic by this fraction to replace it
@@ -83,7 +84,7 @@ def _candidates(mode, g):
             continue
         tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn)
         for s in SPLITS:
-            if s > 1 and (nkt // (s * (2 if cfg >= 7 else 1)) < 2 or s * out * 4 > MAX_SLAB_BYTES):
+            if s > 1 and (nkt // (s * (2 if cfg in (7, 8) else 1)) < 2 or s * out * 4 > MAX_SLAB_BYTES):
                 continue
             if tiles * s > 16384 and s > 1:
                 continue

@@ -461,8 +461,8 @@ static int plan_mode_check(const char* what, int mode) {
 extern "C" int gan_conv_plan_set(int mode, const gan_conv_geom* g, int cfg, int splits) {
     if (int rc = plan_mode_check("gan_conv_plan_set", mode)) return rc;
     if (int rc = conv_geom_check(g)) return rc;
-    GAN_CHECK_ARG(cfg < 0 || (cfg % 16 < 9 && cfg / 16 <= 4),
-                  "gan_conv_plan_set: cfg must be a tile configuration 0..8 plus 16 x a tile order 0..4 (or negative to unpin)");
+    GAN_CHECK_ARG(cfg < 0 || (cfg % 16 < 10 && cfg / 16 <= 4),
+                  "gan_conv_plan_set: cfg must be a tile configuration 0..9 plus 16 x a tile order 0..4 (or negative to unpin)");
     GAN_CHECK_ARG(cfg < 0 || (splits >= 1 && splits <= 512), "gan_conv_plan_set: split factor must be in 1..512");
     return plan_set(mode, *g, cfg, splits);
 }

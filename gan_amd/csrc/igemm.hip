@@ -835,7 +835,8 @@ struct TileCfg {
 
 struct Plan {
     int cfg;  // fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32; split-bf16 MFMA 4: 128x128, 5: 128x64, 6: 64x64,
-              // 7: 128x128 and 8: 128x64 with split-K inside the workgroup (two groups of four waves per tile)
+              // 7: 128x128 and 8: 128x64 with split-K inside the workgroup (two groups of four waves per tile),
+              // 9: 128x32 (outputs of a few channels in the forward and weight-gradient modes)
     int va, vb;
     int splits, kt_per_split;
     int mt, nt;
@@ -844,9 +845,10 @@ struct Plan {
     int order;  // pinned tile order (1 launch order, 2 by row tile, 3 by k range) or 0: chosen by tile_order()
 };
 
-static const TileCfg kCfg[9] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64},
-                                {128, 128}, {128, 64}};
-constexpr int kFirstSplitCfg = 4, kFirstKg2Cfg = 7, kNumCfg = 9;
+static const TileCfg kCfg[10] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64},
+                                 {128, 128}, {128, 64}, {128, 32}};
+constexpr int kFirstSplitCfg = 4, kFirstKg2Cfg = 7, kThinSplitCfg = 9, kNumCfg = 10;
+static bool is_kg2(int cfg) { return cfg == kFirstKg2Cfg || cfg == kFirstKg2Cfg + 1; }
 constexpr int kOrderStride = 16;  // gan_conv_plan_set's cfg argument = tile configuration + 16 * tile order
 
 // Process-wide switch: 1 keeps every contraction on the fp32 MFMA (bitwise an fmaf chain); 0 lets
@@ -947,11 +949,12 @@ static int row3_slices(int mode, const gan_conv_geom& g) {
 
 static bool split_eligible(int mode, const IgemmArgs& a) {
     const gan_conv_geom& g = a.g;
-    // FPROP / WGRAD gather the small side and the filter's cs axis as PAIRS of adjacent channels (8-byte loads), so an
-    // even cs is enough there (138 = 128 + 10 label channels of the y-conditioned MNIST generator); the results then
-    // leave through the dword epilogue.  The big side is read 16 bytes (FPROP) or 8 bytes (WGRAD) at a time.
-    const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0)
-                                         : ((g.cb % 4 == 0 && g.cs % 2 == 0) || row3_slices(mode, g) > 0);
+    // FPROP / WGRAD gather the small side and the filter's cs axis as PAIRS of adjacent channels (8-byte loads at
+    // dword-aligned addresses; the last channel of an odd count on its own), so any cs goes there (138 = 128 + 10
+    // label channels of the y-conditioned MNIST generator, the 3 and 1 channels of CycleGAN's image and patch heads);
+    // results whose rows are not 16-byte multiples leave through the dword epilogue.  The big side is read 16 bytes
+    // (FPROP) or 8 bytes (WGRAD) at a time.
+    const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0) : (g.cb % 4 == 0 || row3_slices(mode, g) > 0);
     return ch && a.a_bytes != 0 && a.b_bytes != 0;
 }
 
@@ -988,7 +991,11 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
     // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4
     const bool split_ok = a_al && b_al && split_eligible(mode, a) && !exact_f32();
-    if (split_ok && pl.cfg < 3) {
+    if (split_ok && pl.cfg == 3 && mode == MODE_FPROP) {
+        // the same tile on the bf16 pipe (CycleGAN's 64 -> 3 channel 7x7 image head: 163 -> 133 us); the weight
+        // gradient of such a layer is faster on the fp32 tile (190 against 245 us) and keeps it
+        pl.cfg = kThinSplitCfg;
+    } else if (split_ok && pl.cfg < 3) {
         // the split kernel converts every staged value, so it wants the largest tile that still leaves
         // enough blocks: 128x128 from 1024 rows on (the tuned DCGAN / CycleGAN plans agree)
         if (N >= 128 && M >= 1024) pl.cfg = 0;
@@ -1017,7 +1024,9 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     }
     if (knobs().force_cfg >= 0) pl.cfg = knobs().force_cfg % kNumCfg;
     // a pinned or forced split configuration on operands that cannot take it (unaligned views, exact mode)
-    if (pl.cfg >= kFirstKg2Cfg && !split_ok) {
+    if (pl.cfg == kThinSplitCfg && (!split_ok || mode == MODE_TPROP)) {
+        pl.cfg = 3;          // (the transposed mode has no 32-wide bf16 tile: thin outputs there run on the vector ALUs)
+    } else if (is_kg2(pl.cfg) && !split_ok) {
         pl.cfg -= kFirstKg2Cfg;
         pinned_splits *= 2;  // a plan tuned for two k groups per workgroup: the one-group kernel wants twice the slabs
     } else if (pl.cfg >= kFirstSplitCfg && !split_ok) {
@@ -1037,11 +1046,11 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     // one co-resident wave of blocks: the fp32 kernel fits 3 blocks per CU, the split kernel 2
     // (LDS and registers allow 2 / 3 / 5 blocks per CU for its 128x128 / 128x64 / 64x64 tiles)
     // (the two-group tiles hold 8 waves each: one 128x128 or two 128x64 workgroups per CU)
-    const long target = pl.cfg == 4 ? 512 : (pl.cfg == 5 ? 768 : (pl.cfg == 6 ? 1280 : (pl.cfg == 7 ? 256 : (pl.cfg == 8 ? 512 : 768))));
+    const long target = pl.cfg == 4 ? 512 : (pl.cfg == 5 ? 768 : (pl.cfg == 6 ? 1280 : (pl.cfg == 7 ? 256 : (pl.cfg == 8 ? 512 : (pl.cfg == 9 ? 1024 : 768)))));
     if (blocks < target) {
         splits = (int)(target / blocks);
         // keep >= 12 k-slices per wave group: shorter loops are all prologue
-        const int kdiv = pl.cfg >= kFirstKg2Cfg ? 24 : 12;
+        const int kdiv = is_kg2(pl.cfg) ? 24 : 12;
         const int max_by_k = nkt / kdiv > 0 ? nkt / kdiv : 1;
         if (splits > max_by_k) splits = max_by_k;
         // the slabs are written once and read once: keep them to a few tens of MB
@@ -1122,21 +1131,21 @@ static void launch_vec(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
 
 // The split kernel's cheap gather arithmetic needs 16-channel alignment of the gathered image (FPROP: big
 // side, TPROP: small side) or, for WGRAD, a small-image width that is a multiple of 4.
-template <int MODE, int BM, int BN, int KG = 1>
+template <int MODE, int BM, int BN, int KG = 1, int WM = 2, int WN = 2>
 static void launch_split(const IgemmArgs& a, dim3 grid, hipStream_t s) {
     const gan_conv_geom& g = a.g;
     const bool fast = (MODE == MODE_FPROP) ? (g.cb % 16 == 0)
                     : (MODE == MODE_TPROP) ? (g.cs % 16 == 0) : (g.ws % 4 == 0);
     if constexpr (MODE != MODE_TPROP) {
         if (a.row3_spr > 0) {
-            hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false, KG, true>), grid, dim3(256 * KG), 0, s, a);
+            hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, WM, WN, false, KG, true>), grid, dim3(256 * KG), 0, s, a);
             return;
         }
     }
     if (fast && !knobs().slow_gather)
-        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, true, KG>), grid, dim3(256 * KG), 0, s, a);
+        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, WM, WN, true, KG>), grid, dim3(256 * KG), 0, s, a);
     else
-        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, 2, 2, false, KG>), grid, dim3(256 * KG), 0, s, a);
+        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, WM, WN, false, KG>), grid, dim3(256 * KG), 0, s, a);
 }
 
 template <int MODE>
@@ -1150,7 +1159,11 @@ static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         case 5: launch_split<MODE, 128, 64>(a, grid, s); break;
         case 6: launch_split<MODE, 64, 64>(a, grid, s); break;
         case 7: launch_split<MODE, 128, 128, 2>(a, grid, s); break;
-        default: launch_split<MODE, 128, 64, 2>(a, grid, s); break;
+        case 8: launch_split<MODE, 128, 64, 2>(a, grid, s); break;
+        default:
+            if constexpr (MODE != MODE_TPROP) launch_split<MODE, 128, 32, 1, 4, 1>(a, grid, s);   // (make_plan maps TPROP to 3)
+            else launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s);
+            break;
     }
 }
 
@@ -1302,8 +1315,8 @@ int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits) {
     if (cfg >= 0 && cfg % kOrderStride >= kFirstSplitCfg) {
         const IgemmArgs a = make_args(mode, g, nullptr, nullptr, nullptr, nullptr, 0);
         GAN_CHECK_ARG(split_eligible(mode, a),
-                      "gan_conv_plan_set: tile configuration %d (bf16 matrix pipe) needs channel counts that are "
-                      "multiples of 4 and operands below 4 GB; this geometry runs configurations 0..3", cfg % kOrderStride);
+                      "gan_conv_plan_set: tile configuration %d (bf16 matrix pipe) needs a gathered-image channel count "
+                      "that is a multiple of 4 and operands below 4 GB; this geometry runs configurations 0..3", cfg % kOrderStride);
     }
     std::lock_guard<std::mutex> lock(g_plan_mu);
     if (cfg < 0) plan_table().erase(plan_key(mode, g));

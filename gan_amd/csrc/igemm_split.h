@@ -72,7 +72,8 @@ template <int MODE, int BM, int BN, int WM, int WN, bool FAST, int KG = 1, bool 
 __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p) {
     static_assert(!ROW3 || (MODE != MODE_TPROP && !FAST), "the filter-row gather serves FPROP and WGRAD, general arithmetic");
     static_assert(WM * WN == 4, "four waves per block");
-    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile sides are multiples of 64");
+    static_assert(BM % 64 == 0 && BN % 32 == 0, "tile sides are multiples of 64 rows and 32 columns");
+    static_assert(BN % 64 == 0 || MODE != MODE_TPROP, "the 32-wide tile has no loader for a k-contiguous B");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr bool A_TRANS = (MODE != MODE_WGRAD);  // A source contiguous along k
     constexpr bool B_TRANS = (MODE == MODE_TPROP);  // B source contiguous along k
@@ -207,6 +208,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         for (int j = 0; j < 4; ++j) b_cj[j] = (unsigned)((b_kq * 4 + j) * N + n0 + 2 * b_rc) * 4u;
     }
     const bool b_pair_valid = b_on & (n0 + 2 * b_rc < N);
+    // an odd N: the last column has no partner (what follows it in memory is the next k row)
+    const bool b_single = !B_TRANS && (n0 + 2 * b_rc + 1 == N);
 
     typedef float AReg[A_PASS][A_W];
     typedef float BReg[B_PASS][B_W];
@@ -393,14 +396,21 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((ta * r3_len + eb) * N * 4);
             const bool kv = kt * BK < kend;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ld2(rsrc_b, (b_pair_valid & kv & (eb + b_kq * 4 + j < r3_len)) ? b_cj[j] + u : kOutOfRange, b_reg[j]);
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = (b_pair_valid & kv & (eb + b_kq * 4 + j < r3_len)) ? b_cj[j] + u : kOutOfRange;
+                if (b_single) { ld1(rsrc_b, off, b_reg[j][0]); b_reg[j][1] = 0.f; }
+                else ld2(rsrc_b, off, b_reg[j]);
+            }
         } else {
             // row-major [K][N]: a constant of the thread per k row plus the slice's scalar offset
             const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane(kt * BK * N * 4);
             const int kb = kt * BK + b_kq * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ld2(rsrc_b, (b_pair_valid & (kb + j < kend)) ? b_cj[j] + u : kOutOfRange, b_reg[j]);
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = (b_pair_valid & (kb + j < kend)) ? b_cj[j] + u : kOutOfRange;
+                if (b_single) { ld1(rsrc_b, off, b_reg[j][0]); b_reg[j][1] = 0.f; }
+                else ld2(rsrc_b, off, b_reg[j]);
+            }
         }
     };
 

@@ -225,7 +225,8 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
  * gan_conv_plan_set pins the tile configuration (fp32 MFMA 0: 128x128, 1: 128x64, 2: 64x64,
  * 3: 128x32; bf16 MFMA on fp32 operands split into three bf16 parts 4: 128x128, 5: 128x64,
  * 6: 64x64, 7: 128x128 and 8: 128x64 with the split-K halved inside the workgroup -- two groups of four waves
- * share one output tile --, all of which need channel counts that are multiples of 4) and
+ * share one output tile --, 9: 128x32 for outputs of a few channels (modes 0 and 2; mode 1 maps it to 3); 4..9 need a
+ * gathered-image channel count that is a multiple of 4, and in mode 1 a small-side count that is one too) and
  * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
  * cfg may carry a tile order as well, cfg = tile configuration + 16 * order: which output tile a workgroup
  * computes as a function of its launch position (workgroups go to the 8 XCDs round robin, each XCD has its own
@@ -256,7 +257,7 @@ int gan_get_exact_f32(void);
  * Each knob takes its initial value from an environment variable, read ONCE at the first call into
  * the library (no getenv on the launch path; a plan cannot change between a workspace query and the
  * call it sizes), and can be changed afterwards with gan_knob_set(name, value):
- *   "force_cfg"       GAN_HIP_FORCE_CFG=<0..8>   tile configuration of every contraction (-1: unset)
+ *   "force_cfg"       GAN_HIP_FORCE_CFG=<0..9>   tile configuration of every contraction (-1: unset)
  *   "force_splits"    GAN_HIP_FORCE_SPLITS=<n>   split-K factor of every contraction (0: unset)
  *   "no_thin"         GAN_HIP_NO_THIN=1          thin outputs (<= 4 channels / linear outputs) stay on the MFMA path
  *   "slow_gather"     GAN_HIP_SLOW_GATHER=1      general gather arithmetic in the split kernel (bit-identical)

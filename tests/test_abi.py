@@ -67,9 +67,9 @@ def test_plan_pinning_is_host_side_bookkeeping():
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     assert get(0) == heur
     assert L.lib.gan_conv_plan_set(3, gp, 0, 1) != 0 and b"mode" in L.lib.gan_last_error()
-    assert L.lib.gan_conv_plan_set(0, gp, 9, 1) != 0
+    assert L.lib.gan_conv_plan_set(0, gp, 10, 1) != 0
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
-    # configurations 4..8 are the split-bf16 kernels (7, 8: split-K inside the workgroup): the heuristic takes them for channel counts that are
+    # configurations 4..9 are the split-bf16 kernels (7, 8: split-K inside the workgroup; 9: 128x32 tile): the heuristic takes them for channel counts that are
     # multiples of 4, a pin is honoured, and the exact-fp32 switch (or an odd channel count) maps them back
     assert heur[0] >= 4 and L.lib.gan_get_exact_f32() == 0
     L.check(L.lib.gan_conv_plan_set(0, gp, 5, 2))
@@ -82,16 +82,16 @@ def test_plan_pinning_is_host_side_bookkeeping():
     # cfg may carry a tile order (16 x order, 1..3); it is reported back in the same encoding
     L.check(L.lib.gan_conv_plan_set(0, gp, 8 + 16 * 2, 2))
     assert get(0)[:2] == (8 + 32, 2)
-    assert L.lib.gan_conv_plan_set(0, gp, 9 + 16, 1) != 0 and L.lib.gan_conv_plan_set(0, gp, 5 + 80, 1) != 0
+    assert L.lib.gan_conv_plan_set(0, gp, 10 + 16, 1) != 0 and L.lib.gan_conv_plan_set(0, gp, 5 + 80, 1) != 0
     L.check(L.lib.gan_conv_plan_set(0, gp, 8, 2))
     L.lib.gan_set_exact_f32(1)
     assert get(0)[:2] == (1, 4)        # two k groups per workgroup fall back to one: twice the slabs
     L.lib.gan_set_exact_f32(0)
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
     godd = L.conv_geom(8, 16, 16, 6, 8, 8, 10, 5, 5, 2, 2, 1, 1)
-    # a geometry that cannot take the split kernels (odd channel counts): the pin is refused, so that
+    # a geometry that cannot take the split kernels (gathered-image channel count no multiple of 4): the pin is refused, so that
     # what is pinned is exactly what runs
-    assert L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 6, 1) != 0 and b"multiples of 4" in L.lib.gan_last_error()
+    assert L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 6, 1) != 0 and b"multiple of 4" in L.lib.gan_last_error()
     L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 2, 1))
     L.check(L.lib.gan_conv_plan_get(0, ctypes.byref(godd), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
     assert c.value == 2

@@ -84,7 +84,14 @@ def test_update_gradients_match_oracle(cond):
     for v in gpu.d_group.variables:
         if is_noise_grad(v.name, d_ref):
             continue        # Adam normalises pure rounding noise to a +-lr step: not comparable
-        assert_close(v.data.cpu().numpy(), ref.st.values[v.name], "post-Adam " + v.name, tol=1e-4, elementwise=False)
+        # Adam's first step is lr * g / (|g| + eps): where |g| is within a few hundred eps = 1e-8 of zero the step
+        # follows the float32 rounding of g, so the 1e-4 bar holds the elements whose gradient is significant
+        # (>= 1e-4 of the variable's largest) and every element stays within the two steps a sign flip can cost
+        got, want, gref = v.data.cpu().numpy(), ref.st.values[v.name], np.abs(d_ref[v.name])
+        sig = (gref >= 1e-4 * gref.max()) | (gref == 0)       # (taps that only ever see padding: no gradient, no step)
+        assert sig.mean() > 0.9, "post-Adam %s: only %.0f %% of the elements are compared" % (v.name, 100 * sig.mean())
+        assert_close(got[sig], want[sig], "post-Adam " + v.name, tol=1e-4, elementwise=False)
+        assert np.abs(got - want).max() <= 2.01 * gpu.d_optim.lr, "post-Adam " + v.name
     for n, v in gpu.store.vars.items():
         if 'moving_' in n:
             # a moving mean near zero is compared on the scale of the matching standard deviation

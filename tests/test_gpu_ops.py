@@ -36,6 +36,9 @@ SMALL_CONVS = [
     (1, 10, 10, 8, 8, 3, 1, 'VALID'),
     (1, 22, 22, 3, 8, 7, 1, 'VALID'),
     (1, 16, 16, 12, 1, 5, 1, 'SAME'),      # cyclegan d_h3_pred: Cout = 1
+    (1, 22, 22, 8, 3, 7, 1, 'VALID'),      # odd Cout on the bf16 kernels: the last column is loaded on its own
+    (1, 40, 36, 64, 3, 7, 1, 'SAME'),      # cyclegan image head 64 -> 3 (128x32 bf16 tile)
+    (2, 9, 13, 8, 5, 5, 2, 'SAME'),
     (2, 9, 13, 8, 12, 5, 2, 'SAME'),       # non-square, odd
     (2, 14, 14, 128, 138, 5, 2, 'SAME'),   # MNIST g_h2 (cs even, not a multiple of 4: pair loads, dword epilogue)
     (2, 9, 13, 8, 10, 5, 2, 'SAME'),
@@ -107,7 +110,7 @@ def test_conv2d_small(L, case):
     _conv_case(L, case)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_conv2d_every_tile_config_and_split(L, cfg, splits):
     _conv_case(L, (2, 12, 12, 8, 40, 5, 2, 'SAME'), cfg, splits)
@@ -246,7 +249,7 @@ def test_deconv2d_small(L, case):
     _deconv_case(L, case)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("splits", [1, 2])
 def test_deconv2d_every_tile_config_and_split(L, cfg, splits):
     _deconv_case(L, (2, 6, 6, 8, 36, 5, 2, 12, 12), cfg, splits)
