@@ -953,8 +953,9 @@ static bool split_eligible(int mode, const IgemmArgs& a) {
     // dword-aligned addresses; the last channel of an odd count on its own), so any cs goes there (138 = 128 + 10
     // label channels of the y-conditioned MNIST generator, the 3 and 1 channels of CycleGAN's image and patch heads);
     // results whose rows are not 16-byte multiples leave through the dword epilogue.  The big side is read 16 bytes
-    // (FPROP) or 8 bytes (WGRAD) at a time.
-    const bool ch = (mode == MODE_TPROP) ? (g.cs % 4 == 0) : (g.cb % 4 == 0 || row3_slices(mode, g) > 0);
+    // (FPROP) or 8 bytes (WGRAD) at a time.  TPROP gathers the small side and the filter along cs, 16 bytes at a time,
+    // or in pairs when cs is even but no multiple of 4.
+    const bool ch = (mode == MODE_TPROP) ? (g.cs % 2 == 0) : (g.cb % 4 == 0 || row3_slices(mode, g) > 0);
     return ch && a.a_bytes != 0 && a.b_bytes != 0;
 }
 

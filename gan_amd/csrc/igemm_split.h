@@ -299,21 +299,33 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 }
             }
         } else if constexpr (A_TRANS) {
-            const int k = kt * BK + t_kq * 4;
-            const bool kv = k < kend;
-            const unsigned uk = kv ? (unsigned)k : 0u;
-            const int tapc = fdiv(uk, dSC);
-            const int cc = uk - tapc * SC;
-            const int ta = fdiv(tapc, dTW);
-            const int tb = tapc - ta * (int)dTW.d;
+            // (pairs: a gathered channel count that is even but no multiple of 4 -- four consecutive k may straddle two
+            // taps, two cannot -- decodes each half of the thread's quad on its own and loads it 8 bytes at a time)
+            const int halves = (MODE == MODE_TPROP && (SC & 3)) ? 2 : 1;
+            for (int hf = 0; hf < halves; ++hf) {
+                const int k = kt * BK + t_kq * 4 + 2 * hf;
+                const bool kv = k < kend;
+                const unsigned uk = kv ? (unsigned)k : 0u;
+                const int tapc = fdiv(uk, dSC);
+                const int cc = uk - tapc * SC;
+                const int ta = fdiv(tapc, dTW);
+                const int tb = tapc - ta * (int)dTW.d;
 #pragma unroll
-            for (int ps = 0; ps < A_PASS; ++ps) {
-                int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
-                int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
-                if (MODE == MODE_FPROP && p.reflect) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
-                const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
-                const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
-                ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
+                for (int ps = 0; ps < A_PASS; ++ps) {
+                    int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
+                    int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
+                    if (MODE == MODE_FPROP && p.reflect) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
+                    const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
+                    const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
+                    if (halves == 1) {
+                        ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
+                    } else {
+                        float two[2];
+                        ld2(rsrc_a, ok ? off : kOutOfRange, two);
+                        a_reg[ps][2 * hf] = two[0];
+                        a_reg[ps][2 * hf + 1] = two[1];
+                    }
+                }
             }
         } else if constexpr (FAST) {
             // the thread's 4 pixels are consecutive in one row of the small image
@@ -374,20 +386,30 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) ld4(rsrc_b, (kv & b_nvalid[ps]) ? b_rb[ps] + u : kOutOfRange, b_reg[ps]);
         } else if constexpr (B_TRANS) {
-            const int k = kt * BK + t_kq * 4;
-            const bool kv = k < kend;
-            const unsigned uk = kv ? (unsigned)k : 0u;
-            const int tapc = fdiv(uk, p.d_cs);
-            const int cc = uk - tapc * g.cs;
-            const int ta = fdiv(tapc, cl.d_kwc);
-            const int tb = tapc - ta * cl.kwc;
-            const int wtap = (cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb);
+            const int halves = (g.cs & 3) ? 2 : 1;   // (pairs, as for A)
+            for (int hf = 0; hf < halves; ++hf) {
+                const int k = kt * BK + t_kq * 4 + 2 * hf;
+                const bool kv = k < kend;
+                const unsigned uk = kv ? (unsigned)k : 0u;
+                const int tapc = fdiv(uk, p.d_cs);
+                const int cc = uk - tapc * g.cs;
+                const int ta = fdiv(tapc, cl.d_kwc);
+                const int tb = tapc - ta * cl.kwc;
+                const int wtap = (cl.ph + g.sh * ta) * g.kw + (cl.pw + g.sw * tb);
 #pragma unroll
-            for (int ps = 0; ps < B_PASS; ++ps) {
-                const int n = n0 + t_r + ps * 64;
-                const bool ok = kv & (n < N);
-                const unsigned off = (unsigned)((wtap * g.cb + n) * g.cs + cc) * 4u;
-                ld4(rsrc_b, ok ? off : kOutOfRange, b_reg[ps]);
+                for (int ps = 0; ps < B_PASS; ++ps) {
+                    const int n = n0 + t_r + ps * 64;
+                    const bool ok = kv & (n < N);
+                    const unsigned off = (unsigned)((wtap * g.cb + n) * g.cs + cc) * 4u;
+                    if (halves == 1) {
+                        ld4(rsrc_b, ok ? off : kOutOfRange, b_reg[ps]);
+                    } else {
+                        float two[2];
+                        ld2(rsrc_b, ok ? off : kOutOfRange, two);
+                        b_reg[ps][2 * hf] = two[0];
+                        b_reg[ps][2 * hf + 1] = two[1];
+                    }
+                }
             }
         } else if constexpr (ROW3 && MODE == MODE_FPROP) {
             // virtual k row r of slice kt = run element e of filter row ta: weight row ta * kw * 3 + e, zeros beyond the run

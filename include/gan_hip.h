@@ -226,7 +226,7 @@ int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n
  * 3: 128x32; bf16 MFMA on fp32 operands split into three bf16 parts 4: 128x128, 5: 128x64,
  * 6: 64x64, 7: 128x128 and 8: 128x64 with the split-K halved inside the workgroup -- two groups of four waves
  * share one output tile --, 9: 128x32 for outputs of a few channels (modes 0 and 2; mode 1 maps it to 3); 4..9 need a
- * gathered-image channel count that is a multiple of 4, and in mode 1 a small-side count that is one too) and
+ * gathered-image channel count that is a multiple of 4; in mode 1 the small-side count must be even) and
  * the split-K factor used for one (mode, geometry) in this process; cfg < 0 removes the pin.
  * cfg may carry a tile order as well, cfg = tile configuration + 16 * order: which output tile a workgroup
  * computes as a function of its launch position (workgroups go to the 8 XCDs round robin, each XCD has its own
