@@ -49,6 +49,8 @@ SIGNATURES = {
     "gan_deconv2d_wgrad": (I, [GeomP, P, P, P, P, I, P, Z, P]),
     "gan_conv2d_fwd_reflect": (I, [GeomP, P, P, P, P, P, Z, P]),
     "gan_conv2d_wgrad_reflect": (I, [GeomP, P, P, P, P, I, P, Z, P]),
+    "gan_conv2d_dgrad_reflect_workspace_bytes": (Z, [GeomP]),
+    "gan_conv2d_dgrad_reflect": (I, [GeomP, P, P, P, P, Z, P]),
     "gan_conv2d_fwd_act": (I, [GeomP, P, P, P, P, I, F, F, F, P, Z, P]),
     "gan_deconv2d_fwd_act": (I, [GeomP, P, P, P, P, I, F, F, F, P, Z, P]),
     "gan_conv2d_dgrad_gated": (I, [GeomP, P, P, P, P, I, F, F, F, P, Z, P]),

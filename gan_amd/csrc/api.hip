@@ -21,6 +21,9 @@ size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                    const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
+size_t igemm_ws_bytes_dgrad_reflect(const gan_conv_geom& g);
+int run_dgrad_reflect(const gan_conv_geom& g, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
+                      hipStream_t s, const char* what);
 int run_igemm_geom_reflect(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                            int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                            const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
@@ -171,6 +174,18 @@ extern "C" int gan_conv2d_wgrad_reflect(const gan_conv_geom* g, const float* x, 
     if (int rc = run_igemm_geom_reflect(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, off, st, what, &job, &done))
         return rc;
     return done ? 0 : colsum_final(job, st, what);
+}
+
+extern "C" size_t gan_conv2d_dgrad_reflect_workspace_bytes(const gan_conv_geom* g) {
+    if (conv_geom_check(g)) return 0;
+    return igemm_ws_bytes_dgrad_reflect(*g);
+}
+
+extern "C" int gan_conv2d_dgrad_reflect(const gan_conv_geom* g, const float* dy, const float* w, float* dx, void* ws,
+                                        size_t ws_bytes, gan_stream_t stream) {
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(dy && w && dx, "gan_conv2d_dgrad_reflect: NULL tensor");
+    return run_dgrad_reflect(*g, dy, w, dx, ws, ws_bytes, as_stream(stream), "gan_conv2d_dgrad_reflect");
 }
 
 // ---------------------------------------------------------------------------- fused activation epilogues

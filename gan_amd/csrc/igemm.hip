@@ -680,6 +680,56 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_scalar_kernel(const flo
     }
 }
 
+// Slab sum and the adjoint of tf.pad(REFLECT) in one pass: the slabs hold the gradient w.r.t. the reflect-padded image
+// ((h + 2p) x (w + 2p)); every pixel of the unpadded image sums the (at most 3 x 3) padded positions that mirror onto it
+// over all slabs, in a fixed order (rows, columns, slabs).
+struct FoldReflect {
+    int n, h, w, c, p;
+};
+
+__global__ void reduce_slabs_fold_reflect_kernel(const float* __restrict__ slabs, float* __restrict__ dx, const FoldReflect f,
+                                                 int splits, long slab_elems) {
+    const int hp = f.h + 2 * f.p, wp = f.w + 2 * f.p;
+    const int cv = (f.c & 3) == 0 ? f.c >> 2 : f.c;   // channels, or channel quads moved 16 bytes at a time
+    const long total = (long)f.n * f.h * f.w * cv;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ch = (int)(i % cv);
+        long r = i / cv;
+        const int sx = (int)(r % f.w); r /= f.w;
+        const int sy = (int)(r % f.h);
+        const int img = (int)(r / f.h);
+        // padded rows that map to sy: sy+p always; p-sy if 1 <= sy <= p; 2(h-1)-sy+p if h-1-p <= sy <= h-2
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = sy + f.p;
+        if (sy >= 1 && sy <= f.p) ys[ny++] = f.p - sy;
+        if (sy <= f.h - 2 && sy >= f.h - 1 - f.p) ys[ny++] = 2 * (f.h - 1) - sy + f.p;
+        xs[nx++] = sx + f.p;
+        if (sx >= 1 && sx <= f.p) xs[nx++] = f.p - sx;
+        if (sx <= f.w - 2 && sx >= f.w - 1 - f.p) xs[nx++] = 2 * (f.w - 1) - sx + f.p;
+        if ((f.c & 3) == 0) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int a = 0; a < ny; ++a)
+                for (int b = 0; b < nx; ++b) {
+                    const float4* src = reinterpret_cast<const float4*>(slabs + (((long)img * hp + ys[a]) * wp + xs[b]) * f.c) + ch;
+                    for (int k = 0; k < splits; ++k) {
+                        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long)k * slab_elems);
+                        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                    }
+                }
+            reinterpret_cast<float4*>(dx)[i] = s;
+        } else {
+            float s = 0.f;
+            for (int a = 0; a < ny; ++a)
+                for (int b = 0; b < nx; ++b) {
+                    const float* src = slabs + (((long)img * hp + ys[a]) * wp + xs[b]) * f.c + ch;
+                    for (int k = 0; k < splits; ++k) s += src[(long)k * slab_elems];
+                }
+            dx[i] = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // TPROP with a thin output (cb <= 4: the image-producing deconv of a generator, the input
 // gradient of a discriminator's first conv).  A 32-wide MFMA tile would be >= 87 % padding in N,
@@ -1198,15 +1248,37 @@ static size_t plan_ws_bytes(const Plan& pl) {
 // Runs one contraction.  `out_c` is the channel count of the output's last axis (bias period).
 // `tail` (optional): a pending column-sum last stage; if the contraction has a slab reduction launch, that launch
 // carries it and *tail_done is set.
+static size_t plan_ws_bytes_fold(const Plan& pl) { return (size_t)(pl.splits > 1 ? pl.splits : 1) * pl.out_elems * sizeof(float); }
+
+static void launch_fold(const float* slabs, float* dx, const FoldReflect& f, int splits, long slab_elems, hipStream_t s) {
+    const long items = (long)f.n * f.h * f.w * ((f.c & 3) == 0 ? f.c >> 2 : f.c);
+    long blocks = (items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_slabs_fold_reflect_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, dx, f, splits, slab_elems);
+}
+
+// `fold` (TPROP only): a.g is the geometry of the reflect-PADDED image; the contraction leaves its result in the
+// workspace (one slab when the plan has no split-K) and the fold kernel writes the gradient of the unpadded image.
 int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
-              const ColsumFinal* tail = nullptr, int* tail_done = nullptr) {
+              const ColsumFinal* tail = nullptr, int* tail_done = nullptr, const FoldReflect* fold = nullptr) {
     ColsumFinal job = ColsumFinal{nullptr, nullptr, 0, 0, 0, 0};
     if (tail != nullptr && tail_done != nullptr && tail->blocks > 0) job = *tail;
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
-    if (mode == MODE_TPROP && thin_tprop_ok(a)) return run_thin_tprop(a, s, what);
+    if (mode == MODE_TPROP && thin_tprop_ok(a)) {
+        if (fold == nullptr) return run_thin_tprop(a, s, what);
+        const long elems = (long)a.g.n * a.g.hb * a.g.wb * a.g.cb;
+        GAN_CHECK_ARG(ws != nullptr && ws_bytes >= (size_t)elems * sizeof(float), "%s: workspace of %zu bytes needed, %zu given",
+                      what, (size_t)elems * sizeof(float), ws_bytes);
+        float* dx = a.out;
+        a.out = static_cast<float*>(ws);
+        if (int rc = run_thin_tprop(a, s, what)) return rc;
+        launch_fold(static_cast<const float*>(ws), dx, *fold, 1, elems, s);
+        return check_launch(what);
+    }
     Plan pl = make_plan(mode, a, aligned16(a.a), aligned16(a.b));
-    const size_t need = plan_ws_bytes(pl);
+    const size_t need = fold ? plan_ws_bytes_fold(pl) : plan_ws_bytes(pl);
     GAN_CHECK_ARG(need == 0 || (ws != nullptr && ws_bytes >= need), "%s: workspace of %zu bytes needed, %zu given",
                   what, need, ws_bytes);
     float* final_out = a.out;
@@ -1218,7 +1290,7 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     a.row3_spr = pl.row3;
     if (pl.row3 && mode == MODE_FPROP) a.K = a.g.kh * pl.row3 * BK;
     if (pl.row3 && mode == MODE_WGRAD) a.M = a.g.kh * pl.row3 * BK;
-    if (pl.splits > 1) {
+    if (pl.splits > 1 || fold != nullptr) {
         a.out = static_cast<float*>(ws);
         a.bias = nullptr;
         a.accumulate = 0;
@@ -1239,6 +1311,10 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         default: launch_cfg<MODE_WGRAD>(a, pl, grid, s); break;
     }
     if (int rc = check_launch(what)) return rc;
+    if (fold != nullptr) {
+        launch_fold(static_cast<const float*>(ws), final_out, *fold, pl.splits, pl.out_elems, s);
+        return check_launch(what);
+    }
     if (pl.splits >= 16 && (pl.out_elems & 3) == 0) {
         const long n4 = pl.out_elems >> 2;
         const int own = (int)((n4 + 15) / 16);
@@ -1369,6 +1445,35 @@ int run_igemm_geom_reflect(int mode, const gan_conv_geom& g, const float* a, con
     IgemmArgs args = make_args(mode, g, a, b, out, bias, accumulate);
     args.reflect = 1;
     return run_igemm(mode, args, out_c, ws, ws_bytes, s, what, tail, tail_done);
+}
+
+// Input gradient of a convolution over a reflect-padded image (`g`: the unpadded image, pad_before = the padding on
+// each side): the transposed contraction on the padded geometry, then the fold back onto the image.
+static gan_conv_geom padded_geom(const gan_conv_geom& g) {
+    gan_conv_geom gp = g;
+    gp.hb = g.hb + 2 * g.pt;
+    gp.wb = g.wb + 2 * g.pl;
+    gp.pt = gp.pl = 0;
+    return gp;
+}
+
+size_t igemm_ws_bytes_dgrad_reflect(const gan_conv_geom& g) {
+    const gan_conv_geom gp = padded_geom(g);
+    IgemmArgs a = make_args(MODE_TPROP, gp, nullptr, nullptr, nullptr, nullptr, 0);
+    build_classes(a.g, a);
+    const size_t al = plan_ws_bytes_fold(make_plan(MODE_TPROP, a, true, true));
+    const size_t un = plan_ws_bytes_fold(make_plan(MODE_TPROP, a, false, false));
+    return al > un ? al : un;
+}
+
+int run_dgrad_reflect(const gan_conv_geom& g, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
+                      hipStream_t s, const char* what) {
+    GAN_CHECK_ARG(g.pt == g.pl && g.pt < g.hb && g.pl < g.wb, "%s: REFLECT padding must be the same on both axes and smaller "
+                  "than the image", what);
+    const gan_conv_geom gp = padded_geom(g);
+    if (int rc = geom_check(gp)) return rc;
+    const FoldReflect f = FoldReflect{g.n, g.hb, g.wb, g.cb, g.pt};
+    return run_igemm(MODE_TPROP, make_args(MODE_TPROP, gp, dy, w, dx, nullptr, 0), g.cb, ws, ws_bytes, s, what, nullptr, nullptr, &f);
 }
 
 // The same with a fused epilogue (activation behind the output, or the activation derivative of a gate tensor).

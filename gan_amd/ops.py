@@ -107,6 +107,14 @@ def _conv_ws(g):
     return _lib.workspace(n)
 
 
+def _reflect_dgrad_ws(g):
+    key = ('r',) + g.key()
+    n = _ws_cache.get(key)
+    if n is None:
+        n = _ws_cache[key] = int(lib.gan_conv2d_dgrad_reflect_workspace_bytes(ctypes.byref(g)))
+    return _lib.workspace(n)
+
+
 def _lin_ws(rows, i, o):
     key = ('l', rows, i, o)
     n = _ws_cache.get(key)
@@ -209,14 +217,12 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if ctx.reflect:
-                # input gradient of the VALID convolution on the reflect-padded image, then folded back onto the image
-                gp = _lib.conv_geom(g.n, g.hb + 2 * g.pt, g.wb + 2 * g.pl, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, 1, 1, 0, 0)
-                wpp, wnp = _conv_ws(gp)
-                dxp = torch.empty((g.n, gp.hb, gp.wb, g.cb), dtype=torch.float32, device=x.device)
-                check(lib.gan_conv2d_dgrad(ctypes.byref(gp), ptr(dy), ptr(w.data), ptr(dxp), wpp, wnp, stream()))
+                # input gradient of the VALID convolution on the reflect-padded image, folded back onto the image by the
+                # kernel that sums the split-K slabs
                 if g.pt != g.pl:
                     raise ValueError("REFLECT padding: square filters only")
-                check(lib.gan_reflect_pad_bwd(ptr(dxp), ptr(dx), g.n, g.hb, g.wb, g.cb, g.pt, stream()))
+                wpp, wnp = _reflect_dgrad_ws(g)
+                check(lib.gan_conv2d_dgrad_reflect(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wpp, wnp, stream()))
             elif ctx.in_tok is None:
                 check(lib.gan_conv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
             else:       # x is the activated output of the layer below: hand it the gradient in front of its activation

@@ -95,12 +95,18 @@ int gan_deconv2d_wgrad(const gan_conv_geom* g, const float* x, const float* dy, 
 /* ---- tf.pad(x, REFLECT) in front of a VALID conv2d (cyclegan_module.py:106-109,124-125,143-144), folded into
  * the convolution's gather: x is the UNPADDED image, the geometry's pad_before (pt, pl) says by how many pixels
  * it is extended by reflection on each side (e.g. hb = hs, kh = 3, sh = 1, pt = 1 for the residual blocks), and
- * a tap outside the image reads the mirrored pixel instead of zero.  Forward and weight gradient; the input
- * gradient is gan_conv2d_dgrad on the padded geometry followed by gan_reflect_pad_bwd. */
+ * a tap outside the image reads the mirrored pixel instead of zero.  The input gradient (gan_conv2d_dgrad_reflect, same
+ * geometry, dx the gradient of the UNPADDED image) is the transposed contraction on the padded geometry, left in the
+ * workspace, and ONE kernel that sums its split-K slabs and folds the mirrored border back onto the image (the adjoint of
+ * the padding); its workspace is sized by gan_conv2d_dgrad_reflect_workspace_bytes.  The two-step form, gan_conv2d_dgrad
+ * on the padded geometry followed by gan_reflect_pad_bwd, gives the same values. */
 int gan_conv2d_fwd_reflect(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                            void* ws, size_t ws_bytes, gan_stream_t stream);
 int gan_conv2d_wgrad_reflect(const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
                              int accumulate, void* ws, size_t ws_bytes, gan_stream_t stream);
+size_t gan_conv2d_dgrad_reflect_workspace_bytes(const gan_conv_geom* g);
+int gan_conv2d_dgrad_reflect(const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                             void* ws, size_t ws_bytes, gan_stream_t stream);
 
 /* ---- conv / deconv with the activation that follows it fused into the store ------------------
  * The reference applies an activation directly to a conv output in its layers without batch norm:

@@ -161,6 +161,32 @@ def test_reflect_padding_folded_into_the_gather(case):
     L.check(L.lib.gan_conv2d_wgrad_reflect(gp, L.ptr(x_d), L.ptr(dy_d), L.ptr(dw), L.ptr(db), 0, wp, wn, L.stream()))
     assert_close(host(dw), T.conv2d_backward_filter(xp, dy.astype(d), k, k, 1, 1, 'VALID'), "conv2d_wgrad_reflect")
     assert_close(host(db), dy.astype(d).sum(axis=(0, 1, 2)), "bias gradient")
+    # input gradient: the transposed contraction on the padded geometry and the fold back onto the image in one call,
+    # against the oracle (gradient of the padded image, mirrored border added onto its sources) and against the two-step
+    # form (gan_conv2d_dgrad on the padded geometry + gan_reflect_pad_bwd), with and without split-K slabs
+    dxp_ref = T.conv2d_backward_input(dy.astype(d), wt.astype(d), xp.shape, 1, 1, 'VALID')
+    dx_ref = np.zeros((n, h, w_, cb))
+    src_y = np.pad(np.arange(h), (p, p), mode='reflect')
+    src_x = np.pad(np.arange(w_), (p, p), mode='reflect')
+    for a_, sy in enumerate(src_y):
+        for b_, sx in enumerate(src_x):
+            dx_ref[:, sy, sx, :] += dxp_ref[:, a_, b_, :]
+    gpad = L.conv_geom(n, h + 2 * p, w_ + 2 * p, cb, h, w_, cs, k, k, 1, 1, 0, 0)
+    from gpu_util import forced
+    for splits in (None, 1, 3):
+        with forced(None, splits):
+            dx = torch.empty(n, h, w_, cb, device='cuda')
+            wq, wqn = L.workspace(int(L.lib.gan_conv2d_dgrad_reflect_workspace_bytes(gp)))
+            L.check(L.lib.gan_conv2d_dgrad_reflect(gp, L.ptr(dy_d), L.ptr(w_d), L.ptr(dx), wq, wqn, L.stream()))
+            assert_close(host(dx), dx_ref, "conv2d_dgrad_reflect (splits %s)" % splits)
+            dxp = torch.empty(n, h + 2 * p, w_ + 2 * p, cb, device='cuda')
+            dx2 = torch.empty_like(dx)
+            wq2, wqn2 = L.workspace(int(L.lib.gan_conv_workspace_bytes(ctypes.byref(gpad))))
+            L.check(L.lib.gan_conv2d_dgrad(ctypes.byref(gpad), L.ptr(dy_d), L.ptr(w_d), L.ptr(dxp), wq2, wqn2, L.stream()))
+            L.check(L.lib.gan_reflect_pad_bwd(L.ptr(dxp), L.ptr(dx2), n, h, w_, cb, p, L.stream()))
+            torch.cuda.synchronize()
+            assert float((dx - dx2).abs().max()) <= 1e-5 * float(dx2.abs().max())
+    assert L.lib.gan_conv2d_dgrad_reflect(gp, L.ptr(dy_d), L.ptr(w_d), L.ptr(dx), wq, 16, L.stream()) != 0   # workspace too small
     # the Python op, both ways
     res = []
     for folded in (True, False):
