@@ -45,7 +45,7 @@ class ContractionTimer(object):
     CONV = ["gan_conv2d_fwd", "gan_conv2d_dgrad", "gan_conv2d_wgrad",
             "gan_deconv2d_fwd", "gan_deconv2d_dgrad", "gan_deconv2d_wgrad",
             "gan_conv2d_fwd_act", "gan_deconv2d_fwd_act", "gan_conv2d_dgrad_gated", "gan_deconv2d_dgrad_gated",
-            "gan_conv2d_fwd_reflect", "gan_conv2d_wgrad_reflect"]
+            "gan_conv2d_fwd_reflect", "gan_conv2d_wgrad_reflect", "gan_conv2d_dgrad_reflect"]
     LIN = ["gan_linear_fwd", "gan_linear_dgrad", "gan_linear_wgrad"]
 
     def __init__(self, L):
