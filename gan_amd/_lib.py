@@ -32,6 +32,12 @@ class ConvGeom(ctypes.Structure):
         return tuple(getattr(self, k) for k, _ in self._fields_)
 
 
+class BnMovingJob(ctypes.Structure):
+    """gan_bn_moving_job of include/gan_hip.h."""
+    _fields_ = [("moving_mean", ctypes.c_void_p), ("moving_var", ctypes.c_void_p), ("save_mean", ctypes.c_void_p),
+                ("save_rstd", ctypes.c_void_p), ("rows", ctypes.c_int), ("c", ctypes.c_int)]
+
+
 GeomP = ctypes.POINTER(ConvGeom)
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
@@ -62,6 +68,7 @@ SIGNATURES = {
     "gan_bn_workspace_bytes": (Z, [I, I, I]),
     "gan_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, I, F, P, Z, P]),
     "gan_bn_moving_update": (I, [P, P, P, P, I, I, F, F, I, P]),
+    "gan_bn_moving_update_multi": (I, [ctypes.POINTER(BnMovingJob), I, F, F, I, P]),
     "gan_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, F, I, F, P]),
     "gan_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, Z, P]),
     "gan_act_fwd": (I, [P, P, L, I, F, F, F, P]),

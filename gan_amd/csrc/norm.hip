@@ -674,6 +674,55 @@ extern "C" int gan_bn_moving_update(float* moving_mean, float* moving_var, const
     return check_launch("gan_bn_moving_update");
 }
 
+// The same for up to kMovingJobs layers in ONE launch (a generator's replay is one such update per batch-norm layer,
+// each a few hundred channels): the jobs travel by value in the kernel-argument segment, blockIdx.y picks the job.
+constexpr int kMovingJobs = 64;
+struct MovingJobs {
+    gan_bn_moving_job job[kMovingJobs];
+};
+
+__global__ void bn_moving_update_multi_kernel(const MovingJobs jobs, float eps, float momentum, int unbiased) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (a runtime index into the by-value argument would copy it to scratch: read the one job from the kernel-argument
+    // segment instead)
+    gan_bn_moving_job j;
+    const MovingJobs* ka = (const MovingJobs*)__builtin_amdgcn_kernarg_segment_ptr();
+    __builtin_memcpy(&j, &ka->job[blockIdx.y], sizeof(j));
+#else
+    const gan_bn_moving_job j = jobs.job[0];
+#endif
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= j.c) return;
+    const float n = (float)j.rows;
+    const float rs = j.save_rstd[ch];
+    float var = fmaxf(1.0f / (rs * rs) - eps, 0.f);
+    if (unbiased) var *= n / fmaxf(n - 1.f, 1.f);
+    j.moving_mean[ch] = j.moving_mean[ch] * momentum + j.save_mean[ch] * (1.f - momentum);
+    j.moving_var[ch] = j.moving_var[ch] * momentum + var * (1.f - momentum);
+}
+
+extern "C" int gan_bn_moving_update_multi(const gan_bn_moving_job* jobs, int count, float eps, float momentum,
+                                          int unbiased_moving_var, gan_stream_t stream) {
+    GAN_CHECK_ARG(jobs != nullptr && count > 0, "gan_bn_moving_update_multi: no jobs");
+    for (int i = 0; i < count; ++i) {
+        GAN_CHECK_ARG(jobs[i].rows > 0 && jobs[i].c > 0, "gan_bn_moving_update_multi: job %d: rows and c must be positive", i);
+        GAN_CHECK_ARG(jobs[i].moving_mean && jobs[i].moving_var && jobs[i].save_mean && jobs[i].save_rstd,
+                      "gan_bn_moving_update_multi: job %d: NULL tensor", i);
+    }
+    for (int first = 0; first < count; first += kMovingJobs) {
+        const int nj = count - first < kMovingJobs ? count - first : kMovingJobs;
+        MovingJobs m;
+        int cmax = 0;
+        for (int i = 0; i < kMovingJobs; ++i) {
+            m.job[i] = jobs[first + (i < nj ? i : 0)];
+            if (i < nj && m.job[i].c > cmax) cmax = m.job[i].c;
+        }
+        hipLaunchKernelGGL(bn_moving_update_multi_kernel, dim3((cmax + 255) / 256, nj), dim3(256), 0, as_stream(stream), m, eps,
+                           momentum, unbiased_moving_var);
+    }
+    return check_launch("gan_bn_moving_update_multi");
+}
+
 extern "C" int gan_bn_fwd_eval(const float* x, const float* gamma, const float* beta, const float* moving_mean,
                                const float* moving_var, float* y, int rows, int c, float eps, int act,
                                float act_param, gan_stream_t stream) {

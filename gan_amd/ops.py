@@ -405,9 +405,16 @@ class moving_update_log(object):
         moving_update_log.current = self.previous
 
     def replay(self):
+        """One launch per 64 layers that share eps / momentum / variance flavour (a whole generator), in log order."""
+        batches = {}
         for mm, mv, mean, rstd, rows, c, eps, momentum, unbiased in self.entries:
-            check(lib.gan_bn_moving_update(ptr(mm.data), ptr(mv.data), ptr(mean), ptr(rstd), rows, c, eps, momentum,
-                                           int(unbiased), stream()))
+            batches.setdefault((float(eps), float(momentum), int(unbiased)), []).append((mm, mv, mean, rstd, rows, c))
+        for (eps, momentum, unbiased), jobs in batches.items():
+            arr = (_lib.BnMovingJob * len(jobs))()
+            for j, (mm, mv, mean, rstd, rows, c) in zip(arr, jobs):
+                j.moving_mean, j.moving_var, j.save_mean, j.save_rstd = ptr(mm.data), ptr(mv.data), ptr(mean), ptr(rstd)
+                j.rows, j.c = int(rows), int(c)
+            check(lib.gan_bn_moving_update_multi(arr, len(jobs), eps, momentum, unbiased, stream()))
 
 
 class _NormFn(torch.autograd.Function):

@@ -163,6 +163,17 @@ int gan_bn_fwd_train(const float* x, const float* gamma, const float* beta, floa
 int gan_bn_moving_update(float* moving_mean, float* moving_var, const float* save_mean,
                          const float* save_rstd, int rows, int c, float eps, float momentum,
                          int unbiased_moving_var, gan_stream_t stream);
+/* The same update for `count` layers with one launch per 64 of them (all with the same eps / momentum / flavour of
+ * variance): the replay of a whole generator is one call. */
+typedef struct {
+    float* moving_mean;
+    float* moving_var;
+    const float* save_mean;
+    const float* save_rstd;
+    int rows, c;
+} gan_bn_moving_job;
+int gan_bn_moving_update_multi(const gan_bn_moving_job* jobs, int count, float eps, float momentum,
+                               int unbiased_moving_var, gan_stream_t stream);
 /* Inference forward (train=False, dcgan.py:427-436): uses the moving statistics. */
 int gan_bn_fwd_eval(const float* x, const float* gamma, const float* beta, const float* moving_mean,
                     const float* moving_var, float* y, int rows, int c, float eps, int act,

@@ -420,6 +420,27 @@ def test_one_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()), msg=lambda m, n=name: n + ": " + m)
 
 
+def test_moving_average_replay_of_many_layers_in_one_call(L):
+    """gan_bn_moving_update_multi moves the averages of many layers with one launch per 64 of them; bit-identical to
+    gan_bn_moving_update layer by layer."""
+    from gan_amd._lib import BnMovingJob
+    torch.manual_seed(11)
+    cs = [int(c) for c in np.random.default_rng(3).integers(1, 700, size=70)]
+    layers = [(torch.randn(c, device='cuda'), torch.rand(c, device='cuda') + 0.5, torch.randn(c, device='cuda'),
+               torch.rand(c, device='cuda') + 0.1, 64 + i) for i, c in enumerate(cs)]
+    single = [(mm.clone(), mv.clone()) for mm, mv, _, _, _ in layers]
+    for (mm, mv), (_, _, mean, rstd, rows), c in zip(single, layers, cs):
+        L.check(L.lib.gan_bn_moving_update(L.ptr(mm), L.ptr(mv), L.ptr(mean), L.ptr(rstd), rows, c, 1e-5, 0.9, 1, L.stream()))
+    arr = (BnMovingJob * len(layers))()
+    for j, (mm, mv, mean, rstd, rows), c in zip(arr, layers, cs):
+        j.moving_mean, j.moving_var, j.save_mean, j.save_rstd, j.rows, j.c = L.ptr(mm), L.ptr(mv), L.ptr(mean), L.ptr(rstd), rows, c
+    L.check(L.lib.gan_bn_moving_update_multi(arr, len(layers), 1e-5, 0.9, 1, L.stream()))
+    torch.cuda.synchronize()
+    for (mm1, mv1), (mm, mv, _, _, _) in zip(single, layers):
+        assert torch.equal(mm1, mm) and torch.equal(mv1, mv)
+    assert L.lib.gan_bn_moving_update_multi(arr, 0, 1e-5, 0.9, 1, L.stream()) != 0
+
+
 def test_batch_norm_unbiased_moving_variance_flag(L):
     from gpu_util import assert_close, dev, host
     shape, c = (8, 4, 4, 16), 16
