@@ -82,6 +82,8 @@ def _candidates(mode, g):
             continue                                  # tile mostly padding in N
         if cfg >= FIRST_SPLIT_CFG and not split_ok:
             continue
+        if cfg == 9 and mode == 1:
+            continue                                  # the 32-wide bf16 tile has no transposed mode
         tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn)
         for s in SPLITS:
             if s > 1 and (nkt // (s * (2 if cfg in (7, 8) else 1)) < 2 or s * out * 4 > MAX_SLAB_BYTES):

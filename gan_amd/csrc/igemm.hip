@@ -1389,6 +1389,9 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
 }
 
 int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits) {
+    GAN_CHECK_ARG(cfg < 0 || cfg % kOrderStride != kThinSplitCfg || mode != MODE_TPROP,
+                  "gan_conv_plan_set: tile configuration %d serves modes 0 and 2 (thin outputs of mode 1 run on the vector "
+                  "ALUs); use 3", kThinSplitCfg);
     if (cfg >= 0 && cfg % kOrderStride >= kFirstSplitCfg) {
         const IgemmArgs a = make_args(mode, g, nullptr, nullptr, nullptr, nullptr, 0);
         GAN_CHECK_ARG(split_eligible(mode, a),

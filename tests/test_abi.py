@@ -83,6 +83,9 @@ def test_plan_pinning_is_host_side_bookkeeping():
     L.check(L.lib.gan_conv_plan_set(0, gp, 8 + 16 * 2, 2))
     assert get(0)[:2] == (8 + 32, 2)
     assert L.lib.gan_conv_plan_set(0, gp, 10 + 16, 1) != 0 and L.lib.gan_conv_plan_set(0, gp, 5 + 80, 1) != 0
+    assert L.lib.gan_conv_plan_set(1, gp, 9, 1) != 0 and b"modes 0 and 2" in L.lib.gan_last_error()
+    L.check(L.lib.gan_conv_plan_set(2, gp, 9, 2))
+    L.check(L.lib.gan_conv_plan_set(2, gp, -1, 0))
     L.check(L.lib.gan_conv_plan_set(0, gp, 8, 2))
     L.lib.gan_set_exact_f32(1)
     assert get(0)[:2] == (1, 4)        # two k groups per workgroup fall back to one: twice the slabs
