@@ -66,6 +66,7 @@ Knobs& knobs() {
         r.slow_gather = getenv("GAN_HIP_SLOW_GATHER") != nullptr;
         r.scalar_epilogue = getenv("GAN_HIP_SCALAR_EPILOGUE") != nullptr;
         r.three_launch_bn = getenv("GAN_HIP_THREE_LAUNCH_BN") != nullptr;
+        r.two_launch_bn = env_int("GAN_HIP_TWO_LAUNCH_BN", 1) != 0;
         r.separate_colsum = getenv("GAN_HIP_SEPARATE_COLSUM") != nullptr;
         r.tile_order = env_int("GAN_HIP_TILE_ORDER", 0);
         r.rgb_gather = env_int("GAN_HIP_RGB_GATHER", 1);
@@ -501,6 +502,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "slow_gather")) k.slow_gather = value != 0;
     else if (!strcmp(name, "scalar_epilogue")) k.scalar_epilogue = value != 0;
     else if (!strcmp(name, "three_launch_bn")) k.three_launch_bn = value != 0;
+    else if (!strcmp(name, "two_launch_bn")) k.two_launch_bn = value != 0;
     else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
     else if (!strcmp(name, "tile_order")) k.tile_order = value;
     else if (!strcmp(name, "rgb_gather")) k.rgb_gather = value;

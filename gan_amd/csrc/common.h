@@ -33,7 +33,8 @@ struct Knobs {
     int no_thin;        // GAN_HIP_NO_THIN: thin outputs stay on the MFMA path
     int slow_gather;    // GAN_HIP_SLOW_GATHER: general gather arithmetic in the split kernel
     int scalar_epilogue;  // GAN_HIP_SCALAR_EPILOGUE: dword stores instead of the 16-byte epilogue
-    int three_launch_bn;  // GAN_HIP_THREE_LAUNCH_BN: small batch norms on the general path
+    int three_launch_bn;  // GAN_HIP_THREE_LAUNCH_BN: every batch norm on the general three-launch path
+    int two_launch_bn;    // GAN_HIP_TWO_LAUNCH_BN: 0 keeps batch norms above 1024 rows per group on the three-launch path
     int separate_colsum;  // GAN_HIP_SEPARATE_COLSUM: bias gradients as launches of their own
     int rgb_gather;       // GAN_HIP_RGB_GATHER: filter-row gather for 3-channel images: 1 FPROP and WGRAD, 2 WGRAD only, 0 off
     int tile_order;       // GAN_HIP_TILE_ORDER: 0 chosen per launch, 1 launch order, 2 by row tile, 3 by k range

@@ -279,7 +279,10 @@ int gan_get_exact_f32(void);
  *   "no_thin"         GAN_HIP_NO_THIN=1          thin outputs (<= 4 channels / linear outputs) stay on the MFMA path
  *   "slow_gather"     GAN_HIP_SLOW_GATHER=1      general gather arithmetic in the split kernel (bit-identical)
  *   "scalar_epilogue" GAN_HIP_SCALAR_EPILOGUE=1  dword stores instead of the 16-byte epilogue
- *   "three_launch_bn" GAN_HIP_THREE_LAUNCH_BN=1  small batch norms (<= 1024 rows per group) on the general path
+ *   "three_launch_bn" GAN_HIP_THREE_LAUNCH_BN=1  every batch norm on the general three-launch path
+ *   "two_launch_bn"   GAN_HIP_TWO_LAUNCH_BN=0    batch norms above 1024 rows per group (channel count a multiple of 64)
+ *                                                on the three-launch path instead of the two-launch kernels whose
+ *                                                apply workgroups merge the block statistics themselves
  *   "separate_colsum" GAN_HIP_SEPARATE_COLSUM=1  bias gradients as two launches after the weight gradient
  *                                                (bit-identical to the default, fused placement)
  *   "tile_order"      GAN_HIP_TILE_ORDER=<0..4>  which tile a contraction workgroup computes: 0 chosen per launch,

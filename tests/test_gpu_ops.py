@@ -420,6 +420,40 @@ def test_one_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()), msg=lambda m, n=name: n + ": " + m)
 
 
+@pytest.mark.parametrize("groups,rows,c", [(1, 16384, 128), (2, 16384, 128), (1, 65536, 64), (1, 4096, 256), (3, 16384, 128),
+                                           (1, 2048, 512), (1, 5001, 64), (2, 1025, 64), (5, 3000, 256)])
+def test_two_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows, c):
+    """Batch norms above 1024 rows per group (channel count a multiple of 64) run as TWO launches: statistics per
+    (row block, 64-channel tile), then an apply kernel whose workgroups merge the block statistics of their tile
+    themselves.  The three-launch path (knob) gives the same results to rounding: outputs, saved statistics, moving
+    averages of stacked passes (moved once per group, in order), input and parameter gradients with accumulation."""
+    torch.manual_seed(groups * 1000 + rows)
+    ga, be = torch.randn(c, device='cuda') * 0.3 + 1, torch.randn(c, device='cuda') * 0.3
+    wp, wn = L.workspace(int(L.lib.gan_bn_workspace_bytes(groups, rows, c)))
+    names = ("y", "mean", "rstd", "moving mean", "moving variance", "dx", "dgamma", "dbeta")
+    for rnd in range(2):
+        x = torch.randn(groups * rows, c, device='cuda') * (1.5 + rnd) + 0.3 * (rnd - 1)
+        res, dy = torch.randn_like(x), torch.randn_like(x)
+        outs = []
+        for general in (False, True):
+            L.knob_set("two_launch_bn", 0 if general else 1)
+            mm, mv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+            y, dx = torch.empty_like(x), torch.empty_like(x)
+            sm, sr = torch.empty(groups * c, device='cuda'), torch.empty(groups * c, device='cuda')
+            dg, db = torch.ones(c, device='cuda'), torch.ones(c, device='cuda')
+            st = L.stream()
+            L.check(L.lib.gan_bn_fwd_train(L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(mm), L.ptr(mv), L.ptr(res), L.ptr(y),
+                                           L.ptr(sm), L.ptr(sr), groups, rows, c, 1e-5, 0.9, 1, 2, 0.2, wp, wn, st))
+            L.check(L.lib.gan_bn_bwd(L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(sm), L.ptr(sr), L.ptr(dy), L.ptr(dx), L.ptr(dg),
+                                     L.ptr(db), 1, groups, rows, c, 2, 0.2, wp, wn, st))
+            torch.cuda.synchronize()
+            outs.append((y, sm, sr, mm, mv, dx, dg, db))
+        L.knob_set("two_launch_bn", 1)
+        for name, a, b in zip(names, outs[0], outs[1]):
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()),
+                                       msg=lambda m, n=name, r=rnd: "round %d, %s: %s" % (r, n, m))
+
+
 def test_moving_average_replay_of_many_layers_in_one_call(L):
     """gan_bn_moving_update_multi moves the averages of many layers with one launch per 64 of them; bit-identical to
     gan_bn_moving_update layer by layer."""
