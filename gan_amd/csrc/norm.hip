@@ -873,9 +873,9 @@ __global__ __launch_bounds__(256) void bn_tile_bwd_apply_kernel(const float* __r
 }
 
 // The two-launch plan of a tensor, or false.
-static bool tile_bn_plan(int groups, int rows, int c, TileBn& s) {
+static bool tile_bn_plan(int groups, int rows, int c, TileBn& s, int min_rows = kFusedMaxRows + 1) {
     if (knobs().three_launch_bn || !knobs().two_launch_bn) return false;
-    if (c % 64 != 0 || rows <= kFusedMaxRows) return false;
+    if (c % 64 != 0 || rows < min_rows) return false;
     const long ctiles = c / 64;
     if (groups * ctiles > 256) return false;
     // (256 workgroups per launch, one per CU, measured best in the DCGAN-64 step: 128 -0.8 %, 512 +1.7 %, 1024 +2.6 %)
@@ -906,7 +906,7 @@ size_t bn_ws_bytes(int groups, int rows, int c) {
     const BnShape s = bn_shape(groups, rows, c);
     size_t blocks = (size_t)s.rblocks;
     TileBn ts;
-    if (tile_bn_plan(groups, rows, c, ts) && (size_t)ts.nb > blocks) blocks = (size_t)ts.nb;
+    if (tile_bn_plan(groups, rows, c, ts, groups > 1 ? 256 : kFusedMaxRows + 1) && (size_t)ts.nb > blocks) blocks = (size_t)ts.nb;
     return ((size_t)groups * blocks * c + (size_t)groups * c) * sizeof(float2);
 }
 
@@ -1081,7 +1081,9 @@ extern "C" int gan_bn_bwd(const float* x, const float* gamma, const float* beta,
     float2* partial = static_cast<float2*>(ws);
     {
         TileBn ts;
-        if (tile_bn_plan(groups, rows, c, ts) && all16({x, dy, dx, save_mean, save_rstd, gamma, beta, dgamma, dbeta, ws})) {
+        // (stacked passes of a small layer have no one-launch backward kernel: they come here too)
+        if (tile_bn_plan(groups, rows, c, ts, groups > 1 ? 256 : kFusedMaxRows + 1) &&
+            all16({x, dy, dx, save_mean, save_rstd, gamma, beta, dgamma, dbeta, ws})) {
             const dim3 grid(ts.nb, c / 64, groups);
             hipLaunchKernelGGL(bn_tile_bwd_sums_kernel, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, partial, ts,
                                act, act_param);

@@ -421,7 +421,7 @@ def test_one_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows
 
 
 @pytest.mark.parametrize("groups,rows,c", [(1, 16384, 128), (2, 16384, 128), (1, 65536, 64), (1, 4096, 256), (3, 16384, 128),
-                                           (1, 2048, 512), (1, 5001, 64), (2, 1025, 64), (5, 3000, 256)])
+                                           (1, 2048, 512), (1, 5001, 64), (2, 1025, 64), (5, 3000, 256), (2, 1024, 512), (3, 300, 64)])
 def test_two_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows, c):
     """Batch norms above 1024 rows per group (channel count a multiple of 64) run as TWO launches: statistics per
     (row block, 64-channel tile), then an apply kernel whose workgroups merge the block statistics of their tile
