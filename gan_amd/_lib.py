@@ -67,9 +67,6 @@ SIGNATURES = {
     "gan_linear_wgrad": (I, [I, I, I, P, P, P, P, I, P, Z, P]),
     "gan_bn_workspace_bytes": (Z, [I, I, I]),
     "gan_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, I, F, P, Z, P]),
-    "gan_conv2d_fwd_deferred": (I, [GeomP, P, P, P, P, P, Z, ctypes.POINTER(ctypes.c_int), P]),
-    "gan_deconv2d_fwd_deferred": (I, [GeomP, P, P, P, P, P, Z, ctypes.POINTER(ctypes.c_int), P]),
-    "gan_bn_fwd_train_slabs": (I, [P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, I, F, P, Z, P]),
     "gan_bn_moving_update": (I, [P, P, P, P, I, I, F, F, I, P]),
     "gan_bn_moving_update_multi": (I, [ctypes.POINTER(BnMovingJob), I, F, F, I, P]),
     "gan_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, F, I, F, P]),

@@ -21,8 +21,6 @@ size_t igemm_ws_bytes_geom(int mode, const gan_conv_geom& g);
 int run_igemm_geom(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
                    int accumulate, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
                    const ColsumFinal* tail = nullptr, int* tail_done = nullptr);
-int run_igemm_geom_deferred(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
-                            int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what, int* deferred);
 size_t igemm_ws_bytes_dgrad_reflect(const gan_conv_geom& g);
 int run_dgrad_reflect(const gan_conv_geom& g, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
                       hipStream_t s, const char* what);
@@ -177,22 +175,6 @@ extern "C" int gan_conv2d_wgrad_reflect(const gan_conv_geom* g, const float* x, 
     if (int rc = run_igemm_geom_reflect(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, off, st, what, &job, &done))
         return rc;
     return done ? 0 : colsum_final(job, st, what);
-}
-
-extern "C" int gan_conv2d_fwd_deferred(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                                       void* ws, size_t ws_bytes, int* slabs, gan_stream_t stream) {
-    if (int rc = conv_geom_check(g)) return rc;
-    GAN_CHECK_ARG(x && w && y && slabs, "gan_conv2d_fwd_deferred: NULL tensor");
-    return run_igemm_geom_deferred(MODE_FPROP, *g, x, w, y, bias, g->cs, ws, ws_bytes, as_stream(stream),
-                                   "gan_conv2d_fwd_deferred", slabs);
-}
-
-extern "C" int gan_deconv2d_fwd_deferred(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                                         void* ws, size_t ws_bytes, int* slabs, gan_stream_t stream) {
-    if (int rc = conv_geom_check(g)) return rc;
-    GAN_CHECK_ARG(x && w && y && slabs, "gan_deconv2d_fwd_deferred: NULL tensor");
-    return run_igemm_geom_deferred(MODE_TPROP, *g, x, w, y, bias, g->cb, ws, ws_bytes, as_stream(stream),
-                                   "gan_deconv2d_fwd_deferred", slabs);
 }
 
 extern "C" size_t gan_conv2d_dgrad_reflect_workspace_bytes(const gan_conv_geom* g) {

@@ -1260,13 +1260,8 @@ static void launch_fold(const float* slabs, float* dx, const FoldReflect& f, int
 
 // `fold` (TPROP only): a.g is the geometry of the reflect-PADDED image; the contraction leaves its result in the
 // workspace (one slab when the plan has no split-K) and the fold kernel writes the gradient of the unpadded image.
-// `deferred` (forward passes whose consumer sums the slabs itself, a batch norm): when the plan has split-K slabs they
-// are left in the workspace, bias NOT added, and *deferred is their number; otherwise the output is complete and
-// *deferred is 0.
 int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what,
-              const ColsumFinal* tail = nullptr, int* tail_done = nullptr, const FoldReflect* fold = nullptr,
-              int* deferred = nullptr) {
-    if (deferred != nullptr) *deferred = 0;
+              const ColsumFinal* tail = nullptr, int* tail_done = nullptr, const FoldReflect* fold = nullptr) {
     ColsumFinal job = ColsumFinal{nullptr, nullptr, 0, 0, 0, 0};
     if (tail != nullptr && tail_done != nullptr && tail->blocks > 0) job = *tail;
     if (mode == MODE_TPROP) build_classes(a.g, a);
@@ -1319,10 +1314,6 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     if (fold != nullptr) {
         launch_fold(static_cast<const float*>(ws), final_out, *fold, pl.splits, pl.out_elems, s);
         return check_launch(what);
-    }
-    if (deferred != nullptr && pl.splits > 1) {
-        *deferred = pl.splits;
-        return 0;
     }
     if (pl.splits >= 16 && (pl.out_elems & 3) == 0) {
         const long n4 = pl.out_elems >> 2;
@@ -1486,24 +1477,6 @@ int run_dgrad_reflect(const gan_conv_geom& g, const float* dy, const float* w, f
     if (int rc = geom_check(gp)) return rc;
     const FoldReflect f = FoldReflect{g.n, g.hb, g.wb, g.cb, g.pt};
     return run_igemm(MODE_TPROP, make_args(MODE_TPROP, gp, dy, w, dx, nullptr, 0), g.cb, ws, ws_bytes, s, what, nullptr, nullptr, &f);
-}
-
-int run_igemm_geom_deferred(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out, const float* bias,
-                            int out_c, void* ws, size_t ws_bytes, hipStream_t s, const char* what, int* deferred) {
-    return run_igemm(mode, make_args(mode, g, a, b, out, bias, 0), out_c, ws, ws_bytes, s, what, nullptr, nullptr, nullptr,
-                     deferred);
-}
-
-// out = sum of `splits` slabs + bias (the fallback of a consumer that cannot sum the slabs itself)
-int reduce_slabs_plain(const float* slabs, float* out, const float* bias, long elems, int c, int splits, hipStream_t s,
-                       const char* what) {
-    long work = (elems + 3) / 4;
-    int blocks = (int)((work + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, out, bias, elems, c, splits, 0, blocks,
-                       ColsumFinal{nullptr, nullptr, 0, 0, 0, 0}, no_epilogue());
-    return check_launch(what);
 }
 
 // The same with a fused epilogue (activation behind the output, or the activation derivative of a gate tensor).

@@ -654,39 +654,19 @@ __device__ __forceinline__ void store_partial_quad(float2* partial, long idx, fl
     pp[1] = make_float4(a.z, b.z, a.w, b.w);
 }
 
-// grid (nb, c / 64, groups); thread = (row lane 0..15, channel quad 0..15).
-// SLABS: x does not exist yet: it is the sum of `nslabs` split-K slabs of the contraction that produces it (each the
-// shape of x, `slab_elems` apart) plus the bias; this kernel forms it, stores it (the apply kernel and the backward
-// pass read it) and takes the statistics on the way, in place of a slab-reduction launch of its own.
-template <bool SLABS>
-__global__ __launch_bounds__(256) void bn_tile_stats_kernel(const float* __restrict__ x, float2* __restrict__ partial, TileBn s,
-                                                            const float* __restrict__ slabs, int nslabs, long slab_elems,
-                                                            const float* __restrict__ bias, float* __restrict__ x_out) {
+// grid (nb, c / 64, groups); thread = (row lane 0..15, channel quad 0..15)
+__global__ __launch_bounds__(256) void bn_tile_stats_kernel(const float* __restrict__ x, float2* __restrict__ partial, TileBn s) {
     __shared__ float4 red[2][256];
     const int quad = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int rb = blockIdx.x, ch0 = blockIdx.y * 64, grp = blockIdx.z;
     const int c4 = s.c >> 2;
     const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
-    const long tile = ((long)grp * s.rows) * s.c + ch0;
-    const float4* xp = reinterpret_cast<const float4*>((SLABS ? slabs : x) + tile) + quad;
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (SLABS && bias != nullptr) bq = reinterpret_cast<const float4*>(bias + ch0)[quad];
-    auto value = [&](int r) -> float4 {
-        float4 v = xp[(long)r * c4];
-        if (SLABS) {
-            for (int k = 1; k < nslabs; ++k)
-                v = f4_add(v, *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xp + (long)r * c4) + (long)k * slab_elems));
-            v = f4_add(v, bq);
-        }
-        return v;
-    };
-    const float4 shift = value(r0);
+    const float4* xp = reinterpret_cast<const float4*>(x + ((long)grp * s.rows) * s.c + ch0) + quad;
+    const float4 shift = xp[(long)r0 * c4];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 16) {
-        const float4 v = value(r);
-        if (SLABS) (reinterpret_cast<float4*>(x_out + tile) + quad)[(long)r * c4] = v;
-        const float4 d = f4_sub(v, shift);
+        const float4 d = f4_sub(xp[(long)r * c4], shift);
         s1 = f4_add(s1, d);
         s2 = f4_fma(d, d, s2);
     }
@@ -974,8 +954,7 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
         if (tile_bn_plan(groups, rows, c, ts) &&
             all16({x, y, residual, save_mean, save_rstd, gamma, beta, moving_mean, moving_var, ws})) {
             const dim3 grid(ts.nb, c / 64, groups);
-            hipLaunchKernelGGL(bn_tile_stats_kernel<false>, grid, dim3(256), 0, st, x, partial, ts, (const float*)nullptr, 0, 0L,
-                               (const float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL(bn_tile_stats_kernel, grid, dim3(256), 0, st, x, partial, ts);
             hipLaunchKernelGGL(bn_tile_apply_kernel, grid, dim3(256), 0, st, x, gamma, beta, moving_mean, moving_var, residual, y,
                                save_mean, save_rstd, (const float2*)partial, ts, eps, momentum, unbiased_moving_var, act, act_param);
             return check_launch("gan_bn_fwd_train");
@@ -998,42 +977,6 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for((c & 3) ? total : total / 4)), dim3(256), 0, st, x, gamma,
                        beta, save_mean, save_rstd, residual, y, groups, rows, c, eps, act, act_param);
     return check_launch("gan_bn_fwd_train");
-}
-
-namespace gan {
-int reduce_slabs_plain(const float* slabs, float* out, const float* bias, long elems, int c, int splits, hipStream_t s,
-                       const char* what);
-}
-
-// Training forward on an input that still lies in `nslabs` split-K slabs (gan_conv2d_fwd_deferred /
-// gan_deconv2d_fwd_deferred): x = sum of the slabs + bias is formed by the statistics kernel (stored to `x`, which the
-// backward pass needs) where the two-launch kernels apply; otherwise a plain slab sum runs first.
-extern "C" int gan_bn_fwd_train_slabs(const float* slabs, int nslabs, const float* bias, float* x, const float* gamma,
-                                      const float* beta, float* moving_mean, float* moving_var, const float* residual, float* y,
-                                      float* save_mean, float* save_rstd, int groups, int rows, int c, float eps,
-                                      float momentum, int unbiased_moving_var, int act, float act_param, void* ws,
-                                      size_t ws_bytes, gan_stream_t stream) {
-    if (int rc = bn_args_check("gan_bn_fwd_train_slabs", groups, rows, c, act)) return rc;
-    GAN_CHECK_ARG(slabs && nslabs >= 1 && x && gamma && beta && y && save_mean && save_rstd, "gan_bn_fwd_train_slabs: NULL tensor");
-    const size_t need = bn_ws_bytes(groups, rows, c);
-    GAN_CHECK_ARG(ws && ws_bytes >= need, "gan_bn_fwd_train_slabs: workspace of %zu bytes needed, %zu given", need, ws_bytes);
-    hipStream_t st = as_stream(stream);
-    const long elems = (long)groups * rows * c;
-    TileBn ts;
-    if (tile_bn_plan(groups, rows, c, ts) &&
-        all16({slabs, bias, x, y, residual, save_mean, save_rstd, gamma, beta, moving_mean, moving_var, ws}) && (elems & 3) == 0) {
-        float2* partial = static_cast<float2*>(ws);
-        const dim3 grid(ts.nb, c / 64, groups);
-        hipLaunchKernelGGL(bn_tile_stats_kernel<true>, grid, dim3(256), 0, st, (const float*)nullptr, partial, ts, slabs, nslabs,
-                           elems, bias, x);
-        hipLaunchKernelGGL(bn_tile_apply_kernel, grid, dim3(256), 0, st, (const float*)x, gamma, beta, moving_mean, moving_var,
-                           residual, y, save_mean, save_rstd, (const float2*)partial, ts, eps, momentum, unbiased_moving_var, act,
-                           act_param);
-        return check_launch("gan_bn_fwd_train_slabs");
-    }
-    if (int rc = reduce_slabs_plain(slabs, x, bias, elems, c, nslabs, st, "gan_bn_fwd_train_slabs")) return rc;
-    return gan_bn_fwd_train(x, gamma, beta, moving_mean, moving_var, residual, y, save_mean, save_rstd, groups, rows, c, eps,
-                            momentum, unbiased_moving_var, act, act_param, ws, ws_bytes, stream);
 }
 
 // moving <- momentum*moving + (1-momentum)*batch from the statistics a training forward saved

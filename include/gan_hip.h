@@ -156,22 +156,6 @@ int gan_bn_fwd_train(const float* x, const float* gamma, const float* beta, floa
                      float* save_rstd, int groups, int rows, int c, float eps, float momentum,
                      int unbiased_moving_var, int act, float act_param, void* ws, size_t ws_bytes,
                      gan_stream_t stream);
-/* conv2d / deconv2d forward whose consumer is a training-mode batch norm (dcgan.py:332-340,368-383: bn(conv2d(...))),
- * with the split-K slab sum left to that consumer: when the plan in effect splits the reduction, the slabs are left
- * at the START of the workspace, the bias is NOT added, y is not written and *slabs is their number (each slab has
- * the shape of y); otherwise y is complete (bias included) and *slabs is 0.  gan_bn_fwd_train_slabs then takes
- * (workspace start, *slabs, bias) in place of x, forms x = sum of the slabs + bias in its statistics pass and stores
- * it to `x` (the backward pass reads it); its own workspace must not overlap the slabs.  One launch fewer per layer
- * pass than gan_conv2d_fwd + gan_bn_fwd_train; same values to float32 rounding of the statistics. */
-int gan_conv2d_fwd_deferred(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                            void* ws, size_t ws_bytes, int* slabs, gan_stream_t stream);
-int gan_deconv2d_fwd_deferred(const gan_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                              void* ws, size_t ws_bytes, int* slabs, gan_stream_t stream);
-int gan_bn_fwd_train_slabs(const float* slabs, int nslabs, const float* bias, float* x, const float* gamma,
-                           const float* beta, float* moving_mean, float* moving_var, const float* residual, float* y,
-                           float* save_mean, float* save_rstd, int groups, int rows, int c, float eps, float momentum,
-                           int unbiased_moving_var, int act, float act_param, void* ws, size_t ws_bytes,
-                           gan_stream_t stream);
 /* The moving-average side effect of one more training forward on the same batch, from the
  * statistics gan_bn_fwd_train saved (groups == 1): what a second sess.run of an unchanged
  * sub-graph does to moving_mean / moving_variance (dcgan.py:228-247 runs the generator once per

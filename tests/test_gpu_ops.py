@@ -454,59 +454,6 @@ def test_two_launch_batch_norm_agrees_with_the_three_launch_path(L, groups, rows
                                        msg=lambda m, n=name, r=rnd: "round %d, %s: %s" % (r, n, m))
 
 
-@pytest.mark.parametrize("kind,case,splits", [("conv", (8, 32, 32, 64, 128, 5, 2, 'SAME'), 3), ("conv", (8, 32, 32, 64, 128, 5, 2, 'SAME'), 1),
-                                              ("deconv", (8, 32, 32, 64, 128, 5, 2, 'SAME'), 4), ("conv", (4, 16, 16, 32, 48, 3, 1, 'SAME'), 2)])
-def test_slab_sum_deferred_to_the_batch_norm_is_bit_identical(L, kind, case, splits):
-    """gan_conv2d_fwd_deferred / gan_deconv2d_fwd_deferred leave their split-K slabs to gan_bn_fwd_train_slabs, whose
-    statistics pass sums them (+ bias) and stores the layer output: same bits as the contraction with its own slab
-    reduction followed by gan_bn_fwd_train, for the layer output, the normalised output and the statistics (also where
-    the batch norm falls back to a plain slab sum: 48 channels are no multiple of 64)."""
-    from gpu_util import dev, forced, geom_for
-    n, h, w_, cb, cs, k, s_, padding = case
-    g = geom_for(n, h, w_, cb, cs, k, s_, padding)
-    gp = ctypes.byref(g)
-    torch.manual_seed(3)
-    wt = torch.randn(k, k, cb, cs, device='cuda') * 0.05
-    if kind == "conv":
-        xin, co, oshape = torch.randn(n, h, w_, cb, device='cuda'), cs, (n, g.hs, g.ws, cs)
-        plain, deferred = L.lib.gan_conv2d_fwd, L.lib.gan_conv2d_fwd_deferred
-    else:
-        xin, co, oshape = torch.randn(n, g.hs, g.ws, cs, device='cuda'), cb, (n, h, w_, cb)
-        plain, deferred = L.lib.gan_deconv2d_fwd, L.lib.gan_deconv2d_fwd_deferred
-    bias = torch.randn(co, device='cuda')
-    rows = oshape[0] * oshape[1] * oshape[2]
-    ga, be = torch.randn(co, device='cuda') * 0.3 + 1, torch.randn(co, device='cuda') * 0.3
-    outs = []
-    with forced(None, splits):
-        conv_need = int(L.lib.gan_conv_workspace_bytes(gp))      # (a forced split factor changes it)
-        off = (conv_need + 255) // 256 * 256
-        bn_need = int(L.lib.gan_bn_workspace_bytes(1, rows, co))
-        wp, wn = L.workspace(off + bn_need)
-        for fused in (False, True):
-            x = torch.full(oshape, float('nan'), device='cuda')
-            y = torch.empty(oshape, device='cuda')
-            sm, sr = torch.empty(co, device='cuda'), torch.empty(co, device='cuda')
-            mm, mv = torch.zeros(co, device='cuda'), torch.ones(co, device='cuda')
-            st = L.stream()
-            if fused:
-                nsl = ctypes.c_int(-1)
-                L.check(deferred(gp, L.ptr(xin), L.ptr(wt), L.ptr(bias), L.ptr(x), wp, conv_need, ctypes.byref(nsl), st))
-                assert nsl.value == (splits if splits > 1 else 0)
-                if nsl.value:
-                    L.check(L.lib.gan_bn_fwd_train_slabs(wp, nsl.value, L.ptr(bias), L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(mm), L.ptr(mv),
-                                                         None, L.ptr(y), L.ptr(sm), L.ptr(sr), 1, rows, co, 1e-5, 0.9, 0, 2, 0.2,
-                                                         wp + off, bn_need, st))
-            if not fused or nsl.value == 0:
-                if not fused:
-                    L.check(plain(gp, L.ptr(xin), L.ptr(wt), L.ptr(bias), L.ptr(x), wp, conv_need, st))
-                L.check(L.lib.gan_bn_fwd_train(L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(mm), L.ptr(mv), None, L.ptr(y), L.ptr(sm),
-                                               L.ptr(sr), 1, rows, co, 1e-5, 0.9, 0, 2, 0.2, wp + off, bn_need, st))
-            torch.cuda.synchronize()
-            outs.append((x, y, sm, sr, mm, mv))
-    for name, a, b in zip(("layer output", "normalised output", "mean", "rstd", "moving mean", "moving variance"), *outs):
-        assert torch.equal(a, b), name
-
-
 def test_moving_average_replay_of_many_layers_in_one_call(L):
     """gan_bn_moving_update_multi moves the averages of many layers with one launch per 64 of them; bit-identical to
     gan_bn_moving_update layer by layer."""
