@@ -340,6 +340,8 @@ __global__ __launch_bounds__(256) void linear_thin_fwd_kernel(const float* __res
     float acc[OUT];
 #pragma unroll
     for (int o = 0; o < OUT; ++o) acc[o] = 0.f;
+    // (unrolled: the loads of eight steps are in flight together; the sums keep their order)
+#pragma unroll 8
     for (int i = threadIdx.x; i < in_dim; i += 256) {
         const float xv = xr[i];
 #pragma unroll
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(256) void linear_thin_wgrad_kernel(const float* __r
     }
     if (db != nullptr && blockIdx.x == 0 && threadIdx.x < OUT) {
         float sum = 0.f;
+#pragma unroll 8
         for (int r = 0; r < rows; ++r) sum += dy[(long)r * OUT + threadIdx.x];
         db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + sum;
     }

@@ -580,6 +580,8 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
         const long n4 = elems >> 2;
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
             float4 s = reinterpret_cast<const float4*>(slabs)[i];
+            // (unrolled: the loads of several slabs are in flight together; the sum keeps its order)
+#pragma unroll 4
             for (int k = 1; k < splits; ++k) {
                 const float4 t = reinterpret_cast<const float4*>(slabs + (long)k * elems)[i];
                 s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
@@ -598,6 +600,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     } else {
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += stride) {
             float s = slabs[i];
+#pragma unroll 4
             for (int k = 1; k < splits; ++k) s += slabs[(long)k * elems + i];
             if (bias) s += bias[(int)(i % c)];
             if (accumulate) s += out[i];
@@ -712,6 +715,7 @@ __global__ void reduce_slabs_fold_reflect_kernel(const float* __restrict__ slabs
             for (int a = 0; a < ny; ++a)
                 for (int b = 0; b < nx; ++b) {
                     const float4* src = reinterpret_cast<const float4*>(slabs + (((long)img * hp + ys[a]) * wp + xs[b]) * f.c) + ch;
+#pragma unroll 4
                     for (int k = 0; k < splits; ++k) {
                         const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long)k * slab_elems);
                         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;

@@ -606,6 +606,7 @@ template <bool MOMENTS>
 __device__ __forceinline__ void tile_bn_sums(const float2* __restrict__ partial, const TileBn& s, int grp, int ch0, int quad,
                                              int rl, float4 shift, float4 (*red)[256], float4& out_a, float4& out_b) {
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+#pragma unroll 4
     for (int b = rl; b < s.nb; b += 16) {
         const float4* pp = reinterpret_cast<const float4*>(partial + ((long)grp * s.nb + b) * s.c + ch0) + 2 * quad;
         const float4 p0 = pp[0], p1 = pp[1];   // {a, b} of channels 0, 1 and of channels 2, 3 of the quad
