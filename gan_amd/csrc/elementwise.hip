@@ -200,6 +200,7 @@ __global__ __launch_bounds__(1024) void loss_kernel(int kind, const float* __res
     float s = 0.f;
     if (vec) {
         const long n4 = n >> 2;
+#pragma unroll 4
         for (long i = threadIdx.x; i < n4; i += blockDim.x) {
             const float4 v = reinterpret_cast<const float4*>(x)[i];
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -261,8 +262,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.f;
-    if (ch < c)
+    if (ch < c) {
+#pragma unroll 8
         for (long r = r0 + ty; r < r1; r += 4) s += x[r * c + ch];
+    }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && ch < c) partial[(long)blockIdx.x * c + ch] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256) void colsum_partial_thin_kernel(const float* _
     float s[C];
 #pragma unroll
     for (int k = 0; k < C; ++k) s[k] = 0.f;
+#pragma unroll 4
     for (long r = r0 + threadIdx.x; r < r1; r += 256) {
 #pragma unroll
         for (int k = 0; k < C; ++k) s[k] += x[r * C + k];

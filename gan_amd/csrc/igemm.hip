@@ -798,18 +798,29 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
 #pragma unroll
     for (int c = 0; c < CB; ++c) acc2[c] = f32x2{0.f, 0.f};
 
-    for (int c0 = 0; c0 < g.cs; c0 += kThinCC) {
-        __syncthreads();
-        // thread -> (halo pixel, 4-channel group); 64 pixels further on every pass, kept as
-        // (row, column) without a division (RW >= 32, so at most two wraps per pass)
-        const int c4 = threadIdx.x & 3;
+    // thread -> (halo pixel, 4-channel group), 64 pixels further on every pass.  The pixel offsets are the same for
+    // every channel chunk, so they are worked out once; the halo of chunk c0 + 16 is fetched into registers before
+    // chunk c0 is multiplied, so its memory latency is hidden behind the FMAs instead of standing between two chunks.
+    constexpr int NP = ((kThinQH + MAXT - 1) * (kThinQW + MAXT - 1) + 63) / 64;
+    const int c4 = threadIdx.x & 3;
+    int off[NP];   // element offset of the pixel in its image; -1: outside the image (zeros); -2: beyond the halo
+    {
         int r = 0, cc = threadIdx.x >> 2;
-        for (int pix = threadIdx.x >> 2; pix < RH * RW; pix += 64, cc += 64) {
-            while (cc >= RW) { cc -= RW; ++r; }
+#pragma unroll
+        for (int t = 0; t < NP; ++t, cc += 64) {
+            while (cc >= RW) { cc -= RW; ++r; }   // RW >= 32: at most two wraps per pass
             const int i = i0 + r, j = j0 + cc;
+            const bool inside = i >= 0 && i < g.hs && j >= 0 && j < g.ws;
+            off[t] = t * 64 + (int)(threadIdx.x >> 2) >= RH * RW ? -2 : (inside ? (i * g.ws + j) * g.cs + c4 * 4 : -1);
+        }
+    }
+    float4 halo[NP];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i >= 0 && i < g.hs && j >= 0 && j < g.ws) {
-                const float* src = in_img + ((long)i * g.ws + j) * g.cs + c0 + c4 * 4;
+            if (off[t] >= 0) {
+                const float* src = in_img + off[t] + c0;
                 if constexpr (!TAIL) {
                     v = *reinterpret_cast<const float4*>(src);
                 } else {
@@ -820,8 +831,16 @@ __global__ __launch_bounds__(256) void tprop_thin_kernel(const ThinArgs p) {
                     if (left > 3) v.w = src[3];
                 }
             }
-            *reinterpret_cast<float4*>(&tile[pix * kThinPix + c4 * 4]) = v;
+            halo[t] = v;
         }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < g.cs; c0 += kThinCC) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+            if (off[t] != -2) *reinterpret_cast<float4*>(&tile[(t * 64 + (threadIdx.x >> 2)) * kThinPix + c4 * 4]) = halo[t];
+        if (c0 + kThinCC < g.cs) fetch(c0 + kThinCC);
         __syncthreads();
         for (int ta = 0; ta < khc; ++ta)
             for (int tb = 0; tb < kwc; ++tb) {
@@ -1127,6 +1146,7 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
 static bool thin_tprop_ok(const IgemmArgs& a) {
     const gan_conv_geom& g = a.g;
     if (g.cb > 4 || a.accumulate) return false;
+    if ((long)g.hs * g.ws * g.cs >= (1L << 31)) return false;   // the kernel keeps pixel offsets within an image as ints
     if (knobs().force_cfg >= 0 || knobs().no_thin) return false;
     for (int i = 0; i < a.ncls; ++i)
         if (a.cls[i].khc > kThinMaxTaps || a.cls[i].kwc > kThinMaxTaps) return false;
