@@ -284,7 +284,7 @@ def test_deconv2d_is_adjoint_of_conv2d_on_device(L):
 @pytest.mark.parametrize("rows,i,o", [(64, 100, 8192), (64, 8192, 1), (64, 110, 1024), (64, 1034, 6272),
                                       (64, 3636, 1024), (5, 7, 3), (64, 1024, 256),
                                       # a handful of outputs: the matrix-vector kernels
-                                      (64, 1034, 1), (128, 8192, 1), (9, 300, 3), (7, 513, 4), (8, 256, 2)])
+                                      (64, 1034, 1), (128, 8192, 1), (9, 300, 3), (7, 513, 4), (8, 256, 2), (2, 260, 1)])
 def test_linear(L, rows, i, o):
     from gpu_util import assert_close, dev, host
     x = RNG.standard_normal((rows, i)).astype(np.float32)
@@ -311,6 +311,25 @@ def test_linear(L, rows, i, o):
     torch.cuda.synchronize()
     assert_close(host(dm), 2 * dm_ref, "linear wgrad accumulate")
     assert_close(host(db), 2 * db_ref, "linear bias grad accumulate")
+
+
+def test_thin_linear_forward_takes_rows_and_vectors_at_any_dword_address(L):
+    """The single-output forward moves 16 bytes per lane only when the rows and the vector allow it."""
+    from gpu_util import assert_close, dev, host
+    rows, i = 6, 512
+    x = RNG.standard_normal((rows, i)).astype(np.float32)
+    m = (RNG.standard_normal((i, 1)) * 0.05).astype(np.float32)
+    y_ref = T.linear_forward(x.astype(np.float64), m.astype(np.float64), np.zeros(1))
+    xbuf, mbuf = torch.empty(rows * i + 1, device='cuda'), torch.empty(i + 1, device='cuda')
+    xbuf[1:].copy_(dev(x).reshape(-1))
+    mbuf[1:].copy_(dev(m).reshape(-1))
+    xd, md = dev(x), dev(m)
+    y = torch.empty((rows, 1), device='cuda')
+    for xp, mp in [(xbuf.data_ptr() + 4, L.ptr(md)), (L.ptr(xd), mbuf.data_ptr() + 4), (xbuf.data_ptr() + 4, mbuf.data_ptr() + 4)]:
+        y.fill_(7.0)
+        L.check(L.lib.gan_linear_fwd(rows, i, 1, xp, mp, None, L.ptr(y), None, 0, L.stream()))
+        torch.cuda.synchronize()
+        assert_close(host(y), y_ref, "thin linear fwd, unaligned")
 
 
 ACTS = [(0, 0.0), (1, 0.0), (2, 0.2), (3, 0.0), (4, 0.0)]
