@@ -81,6 +81,8 @@ SIGNATURES = {
     "gan_sigmoid_bce_mean": (I, [P, L, F, F, I, P, P, P]),
     "gan_mse_const_mean": (I, [P, L, F, F, I, P, P, P]),
     "gan_l1_mean": (I, [P, P, L, F, I, P, P, P]),
+    "gan_l1_mean_workspace_bytes": (Z, [L]),
+    "gan_l1_mean_ws": (I, [P, P, L, F, I, P, P, P, Z, P]),
     "gan_adam_tf_step": (I, [P, P, P, P, L, F, F, F, F, F, P, P, P]),
     "gan_fill": (I, [P, L, F, P]),
     "gan_conv_plan_set": (I, [I, GeomP, I, I]),

@@ -226,6 +226,57 @@ __global__ __launch_bounds__(1024) void loss_kernel(int kind, const float* __res
     if (threadIdx.x == 0) loss_out[0] = (accumulate ? loss_out[0] : 0.f) + weight * tot * inv_n;
 }
 
+// Image-sized terms (CycleGAN's cycle loss over 256 x 256 x 3 values): one block is one CU's worth of memory
+// bandwidth, so with a workspace from the caller the elementwise work is spread over up to 256 blocks, each leaves
+// the sum of its contiguous range in the workspace, and a second launch adds the block sums in block order.
+constexpr int kLossMaxBlocks = 256;
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float* __restrict__ x, const float* __restrict__ x2,
+                                                           long n, long per_block, float t, float weight, int vec,
+                                                           float* __restrict__ partial, float* __restrict__ g1) {
+    __shared__ float red[4];
+    const float gs = weight * (1.0f / (float)n);
+    const long e0 = (long)blockIdx.x * per_block;            // per_block is a multiple of 4
+    const long e1 = e0 + per_block < n ? e0 + per_block : n;
+    float s = 0.f;
+    if (vec) {
+#pragma unroll 4
+        for (long i = (e0 >> 2) + threadIdx.x; i < (e1 >> 2); i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kind == 2) w = reinterpret_cast<const float4*>(x2)[i];
+            float p0, p1, p2, p3;
+            float4 g;
+            loss_term(kind, v.x, w.x, t, p0, g.x);
+            loss_term(kind, v.y, w.y, t, p1, g.y);
+            loss_term(kind, v.z, w.z, t, p2, g.z);
+            loss_term(kind, v.w, w.w, t, p3, g.w);
+            s += (p0 + p1) + (p2 + p3);
+            if (g1) reinterpret_cast<float4*>(g1)[i] = make_float4(gs * g.x, gs * g.y, gs * g.z, gs * g.w);
+        }
+    } else {
+#pragma unroll 4
+        for (long i = e0 + threadIdx.x; i < e1; i += 256) {
+            float per, g;
+            loss_term(kind, x[i], kind == 2 ? x2[i] : 0.f, t, per, g);
+            s += per;
+            if (g1) g1[i] = gs * g;
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void loss_final_kernel(const float* __restrict__ partial, int blocks, long n, float weight,
+                                                        int accumulate, float* __restrict__ loss_out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < blocks; i += 64) s += partial[i];   // at most 4 per lane
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss_out[0] = (accumulate ? loss_out[0] : 0.f) + weight * s * (1.0f / (float)n);
+}
+
 // ------------------------------------------------------------------ column sums (bias gradient)
 // partial[rb][c] per row block, then one wave per channel sums the partials (fixed shuffle tree).
 // float4 path (c % 4 == 0 and c/4 divides 256): thread = (row lane, 4-channel group).
@@ -522,6 +573,28 @@ extern "C" int gan_l1_mean(const float* a, const float* b, long n, float weight,
                            float* db, gan_stream_t stream) {
     GAN_CHECK_ARG(b, "gan_l1_mean: NULL tensor");
     return launch_loss("gan_l1_mean", 2, a, b, n, 0.f, weight, accumulate, loss_out, db, stream);
+}
+
+extern "C" size_t gan_l1_mean_workspace_bytes(long n) { return n > 0 ? kLossMaxBlocks * sizeof(float) : 0; }
+
+extern "C" int gan_l1_mean_ws(const float* a, const float* b, long n, float weight, int accumulate, float* loss_out,
+                              float* db, void* ws, size_t ws_bytes, gan_stream_t stream) {
+    GAN_CHECK_ARG(a && b && loss_out && n > 0, "gan_l1_mean_ws: NULL tensor or n <= 0");
+    GAN_CHECK_ARG(ws != nullptr && ws_bytes >= gan_l1_mean_workspace_bytes(n), "gan_l1_mean_ws: workspace of %zu bytes needed, %zu given",
+                  gan_l1_mean_workspace_bytes(n), ws_bytes);
+    GAN_CHECK_ARG((reinterpret_cast<size_t>(ws) & 3) == 0, "gan_l1_mean_ws: workspace must be 4-byte aligned");
+    const auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
+    const int vec = ((n & 3) == 0 && al(a) && al(b) && al(db)) ? 1 : 0;
+    // contiguous ranges of at least 4096 values, a multiple of 4 each, at most kLossMaxBlocks of them
+    long per_block = (n + kLossMaxBlocks - 1) / kLossMaxBlocks;
+    if (per_block < 4096) per_block = 4096;
+    per_block = (per_block + 3) & ~3L;
+    const int blocks = (int)((n + per_block - 1) / per_block);
+    float* partial = static_cast<float*>(ws);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, 2, a, b, n, per_block, 0.f, weight, vec, partial, db);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partial, blocks, n, weight, accumulate, loss_out);
+    return check_launch("gan_l1_mean_ws");
 }
 
 extern "C" int gan_adam_tf_step(float* theta, const float* grad, float* m, float* v, long n, float lr, float beta1,

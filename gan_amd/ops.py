@@ -681,6 +681,9 @@ def reflect_pad(x, p):
 # losses.  Each is fused with its gradient and is a ROOT of the backward pass: the value handed
 # to backward() is taken to be 1 and the loss's weight in the objective is the `weight` argument.
 # --------------------------------------------------------------------------------------------
+_L1_MANY_BLOCKS = 32768   # values from which the L1 term takes the multi-block kernels
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kind, x, other, target, weight):
@@ -695,7 +698,11 @@ class _LossFn(torch.autograd.Function):
             check(lib.gan_mse_const_mean(ptr(x), n, target, weight, 0, ptr(loss), ptr(grad), stream()))
         else:   # l1: x = a (reference side), other = b; the kernel emits d/db
             other = _dense(other)
-            check(lib.gan_l1_mean(ptr(x), ptr(other), n, weight, 0, ptr(loss), ptr(grad), stream()))
+            if n >= _L1_MANY_BLOCKS:   # image-sized: spread over the chip, block sums through the workspace
+                wp, wn = _lib.workspace(int(lib.gan_l1_mean_workspace_bytes(n)))
+                check(lib.gan_l1_mean_ws(ptr(x), ptr(other), n, weight, 0, ptr(loss), ptr(grad), wp, wn, stream()))
+            else:
+                check(lib.gan_l1_mean(ptr(x), ptr(other), n, weight, 0, ptr(loss), ptr(grad), stream()))
         ctx.kind = kind
         ctx.grad = grad
         return loss

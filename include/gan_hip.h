@@ -222,6 +222,13 @@ int gan_mse_const_mean(const float* x, long n, float target, float weight, int a
                        float* loss_out, float* dx, gan_stream_t stream);
 int gan_l1_mean(const float* a, const float* b, long n, float weight, int accumulate,
                 float* loss_out, float* db, gan_stream_t stream);
+/* gan_l1_mean for image-sized terms (the cycle loss over whole 256 x 256 x 3 images, cyclegan.py:103-106 through
+ * cyclegan_module.py:149-150): with a workspace of gan_l1_mean_workspace_bytes(n) bytes the elementwise work runs on up
+ * to 256 workgroups instead of one, each leaves the sum of its contiguous range in the workspace and a second launch
+ * adds those in block order.  Same results as gan_l1_mean up to the order of the fp32 sum; deterministic. */
+size_t gan_l1_mean_workspace_bytes(long n);
+int gan_l1_mean_ws(const float* a, const float* b, long n, float weight, int accumulate,
+                   float* loss_out, float* db, void* ws, size_t ws_bytes, gan_stream_t stream);
 
 /* ---- tf.train.AdamOptimizer(lr, beta1).minimize (dcgan.py:154-157) ----------------------
  * One fused step over a flat parameter group.  step_dev[0] (device int32) holds the number of

@@ -604,6 +604,18 @@ def test_losses(L):
         l1, g1 = T.l1_mean(x.astype(np.float64), b.astype(np.float64))
         assert_close(host(loss), [10 * l1], "l1 loss")
         assert_close(host(g), -10 * g1, "l1 grad w.r.t. b")
+        # the multi-block form: block sums through a workspace, any n and alignment
+        wp, wn = L.workspace(int(L.lib.gan_l1_mean_workspace_bytes(n)))
+        for acc in (0, 1):
+            g.fill_(7.0)
+            L.check(L.lib.gan_l1_mean_ws(L.ptr(xd), L.ptr(bd), n, 10.0, acc, L.ptr(loss), L.ptr(g), wp, wn, L.stream()))
+            torch.cuda.synchronize()
+            assert_close(host(loss), [10 * l1 * (1 + acc)], "l1 loss, multi-block")
+            assert_close(host(g), -10 * g1, "l1 grad w.r.t. b, multi-block")
+        L.check(L.lib.gan_l1_mean_ws(L.ptr(xd), L.ptr(bd), n, 10.0, 0, L.ptr(loss), None, wp, wn, L.stream()))
+        torch.cuda.synchronize()
+        assert_close(host(loss), [10 * l1], "l1 loss, multi-block, no gradient")
+        assert L.lib.gan_l1_mean_ws(L.ptr(xd), L.ptr(bd), n, 10.0, 0, L.ptr(loss), None, wp, 8, L.stream()) != 0   # workspace too small
 
 
 def test_adam_tf_steps(L):
