@@ -1,8 +1,8 @@
 // extern "C" entry points of the contraction family (conv2d, conv2d_transpose, linear)
 // and the library-wide error channel.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 
 #include "common.h"
 
@@ -246,24 +246,23 @@ namespace gan {
 constexpr size_t kScratchBytes = 64u << 20;
 constexpr int kScratchMaxDevices = 64;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
-static void* g_scratch_ptr[kScratchMaxDevices];
-static std::mutex g_scratch_mu;
+static std::atomic<void*> g_scratch_ptr[kScratchMaxDevices];
 
-// Device address of `scratch` on the current device (looked up at the first call on that device).
+// Device address of `scratch` on the current device: looked up at the first call on that device, read without a lock
+// from then on (two threads that race on the first call ask twice and store the same address).
 static int scratch_address(void** out, const char* what) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     GAN_CHECK_ARG(e == hipSuccess, "%s: hipGetDevice failed: %s", what, hipGetErrorString(e));
     GAN_CHECK_ARG(dev >= 0 && dev < kScratchMaxDevices, "%s: device index %d outside 0..%d", what, dev, kScratchMaxDevices - 1);
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    if (g_scratch_ptr[dev] == nullptr) {
-        void* p = nullptr;
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         GAN_CHECK_ARG(e == hipSuccess && p != nullptr, "%s: hipGetSymbolAddress(scratch) failed on device %d: %s", what, dev,
                       hipGetErrorString(e));
-        g_scratch_ptr[dev] = p;
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
     }
-    *out = g_scratch_ptr[dev];
+    *out = p;
     return 0;
 }
 }  // namespace gan

@@ -1497,6 +1497,13 @@ int run_dgrad_reflect(const gan_conv_geom& g, const float* dy, const float* w, f
                       hipStream_t s, const char* what) {
     GAN_CHECK_ARG(g.pt == g.pl && g.pt < g.hb && g.pl < g.wb, "%s: REFLECT padding must be the same on both axes and smaller "
                   "than the image", what);
+    // The padded geometry below extends the image by pt / pl on BOTH sides and the fold mirrors about those borders:
+    // that is the adjoint of the forward pass only when the filter covers the padded image exactly (tf.pad by p on
+    // each side + VALID).  A geometry with a different implicit pad behind the image (even filters, stride 2 with a
+    // ragged end) would make this silently something else than the forward pass's adjoint: refuse it.
+    GAN_CHECK_ARG((g.hs - 1) * g.sh + g.kh == g.hb + 2 * g.pt && (g.ws - 1) * g.sw + g.kw == g.wb + 2 * g.pl,
+                  "%s: the filter must cover the reflect-padded image exactly ((hs-1)*sh+kh == hb+2*pt and the same along "
+                  "the width): symmetric REFLECT padding in front of a VALID convolution", what);
     const gan_conv_geom gp = padded_geom(g);
     if (int rc = geom_check(gp)) return rc;
     const FoldReflect f = FoldReflect{g.n, g.hb, g.wb, g.cb, g.pt};

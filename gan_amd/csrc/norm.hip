@@ -1038,6 +1038,16 @@ extern "C" int gan_bn_moving_update_multi(const gan_bn_moving_job* jobs, int cou
         GAN_CHECK_ARG(jobs[i].moving_mean && jobs[i].moving_var && jobs[i].save_mean && jobs[i].save_rstd,
                       "gan_bn_moving_update_multi: job %d: NULL tensor", i);
     }
+    // the jobs of one launch run concurrently: two of them on the same averages would lose one update
+    for (int first = 0; first < count; first += kMovingJobs) {
+        const int nj = count - first < kMovingJobs ? count - first : kMovingJobs;
+        for (int i = 1; i < nj; ++i)
+            for (int j = 0; j < i; ++j)
+                GAN_CHECK_ARG(jobs[first + i].moving_mean != jobs[first + j].moving_mean &&
+                              jobs[first + i].moving_var != jobs[first + j].moving_var,
+                              "gan_bn_moving_update_multi: jobs %d and %d update the same moving averages; a layer that moves "
+                              "twice needs two calls", first + j, first + i);
+    }
     for (int first = 0; first < count; first += kMovingJobs) {
         const int nj = count - first < kMovingJobs ? count - first : kMovingJobs;
         MovingJobs m;

@@ -145,11 +145,14 @@ class _ActToken(object):
     deconv that takes that output as its input multiplies the input gradient it produces by the activation's
     derivative on store (the gated input-gradient entry points) and notes the gradient tensor here; the
     producing layer's backward then finds its incoming gradient already taken through the activation."""
-    __slots__ = ('spec', 'grad_ptr')
+    __slots__ = ('spec', 'gated')
 
     def __init__(self, spec):
         self.spec = spec          # (activation code, parameter, scale, shift)
-        self.grad_ptr = None      # data pointer of the gradient a gated consumer produced
+        self.gated = None         # (gradient tensor a gated consumer produced, its version counter at that time)
+
+    def note_gated(self, dx):
+        self.gated = (dx, dx._version)
 
 
 def _act_spec(act, act_param, act_scale, act_shift):
@@ -163,14 +166,18 @@ def _through_own_activation(ctx, y, dy):
     """Gradient w.r.t. the contraction output in front of a fused activation, from the gradient w.r.t. the
     activated output y."""
     tok = ctx.act_tok
-    if tok.grad_ptr is not None:
-        ptr_, tok.grad_ptr = tok.grad_ptr, None
-        if dy.data_ptr() != ptr_:
+    if tok.gated is not None:
+        (dx, version), tok.gated = tok.gated, None
+        # The incoming gradient must be the gated consumer's tensor, untouched.  A second consumer's gradient is either
+        # summed into a new tensor (another address) or, when autograd owns the only reference, added IN PLACE into dx
+        # (same address, version counter moved): both are refused.
+        if dy.data_ptr() != dx.data_ptr() or dy._version != version:
             raise RuntimeError("the output of a conv / deconv with a fused activation feeds a gated consumer AND something "
                                "else: their gradients were summed after one of them had been taken through the "
                                "activation; apply the activation as an op of its own (ops.lrelu / tanh / ...) here")
         return dy                 # the consumer's input-gradient epilogue has applied the derivative
     code, param, scale, shift = tok.spec
+    dy = _dense(dy)
     dz = torch.empty_like(y)
     check(lib.gan_act_bwd(ptr(y), ptr(dy), ptr(dz), y.numel(), code, param, scale, shift, stream()))
     return dz
@@ -203,9 +210,9 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x = ctx.saved_tensors[0]
         w, b, g = ctx.w, ctx.b, ctx.g
-        dy = _dense(dy)
         if ctx.act_tok is not None:
             dy = _through_own_activation(ctx, ctx.saved_tensors[1], dy)
+        dy = _dense(dy)
         wp, wn = _conv_ws(g)
         if w.wants_grad:
             dw, acc = w.grad_target()
@@ -229,7 +236,7 @@ class _Conv2dFn(torch.autograd.Function):
                 code, param, scale, shift = ctx.in_tok.spec
                 check(lib.gan_conv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param, scale,
                                                  shift, wp, wn, stream()))
-                ctx.in_tok.grad_ptr = dx.data_ptr()
+                ctx.in_tok.note_gated(dx)
         return dx, None, None, None, None, None, None, None
 
 
@@ -254,9 +261,9 @@ class _Deconv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x = ctx.saved_tensors[0]
         w, b, g = ctx.w, ctx.b, ctx.g
-        dy = _dense(dy)
         if ctx.act_tok is not None:
             dy = _through_own_activation(ctx, ctx.saved_tensors[1], dy)
+        dy = _dense(dy)
         wp, wn = _conv_ws(g)
         if w.wants_grad:
             dw, acc = w.grad_target()
@@ -272,7 +279,7 @@ class _Deconv2dFn(torch.autograd.Function):
                 code, param, scale, shift = ctx.in_tok.spec
                 check(lib.gan_deconv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param,
                                                    scale, shift, wp, wn, stream()))
-                ctx.in_tok.grad_ptr = dx.data_ptr()
+                ctx.in_tok.note_gated(dx)
         return dx, None, None, None, None, None, None
 
 
@@ -405,11 +412,18 @@ class moving_update_log(object):
         moving_update_log.current = self.previous
 
     def replay(self):
-        """One launch per 64 layers that share eps / momentum / variance flavour (a whole generator), in log order."""
-        batches = {}
+        """The logged updates again, in log order.  Layers that share eps / momentum / variance flavour go into one
+        launch (a whole generator); the jobs of a launch run concurrently, so a layer that is logged twice (its
+        moving averages must move twice, one after the other) starts a new launch."""
+        batches = []
         for mm, mv, mean, rstd, rows, c, eps, momentum, unbiased in self.entries:
-            batches.setdefault((float(eps), float(momentum), int(unbiased)), []).append((mm, mv, mean, rstd, rows, c))
-        for (eps, momentum, unbiased), jobs in batches.items():
+            key = (float(eps), float(momentum), int(unbiased))
+            targets = (mm.data.data_ptr(), mv.data.data_ptr())
+            if not batches or batches[-1][0] != key or any(t in batches[-1][2] for t in targets):
+                batches.append((key, [], set()))
+            batches[-1][1].append((mm, mv, mean, rstd, rows, c))
+            batches[-1][2].update(targets)
+        for (eps, momentum, unbiased), jobs, _ in batches:
             arr = (_lib.BnMovingJob * len(jobs))()
             for j, (mm, mv, mean, rstd, rows, c) in zip(arr, jobs):
                 j.moving_mean, j.moving_var, j.save_mean, j.save_rstd = ptr(mm.data), ptr(mv.data), ptr(mean), ptr(rstd)

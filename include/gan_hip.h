@@ -164,7 +164,9 @@ int gan_bn_moving_update(float* moving_mean, float* moving_var, const float* sav
                          const float* save_rstd, int rows, int c, float eps, float momentum,
                          int unbiased_moving_var, gan_stream_t stream);
 /* The same update for `count` layers with one launch per 64 of them (all with the same eps / momentum / flavour of
- * variance): the replay of a whole generator is one call. */
+ * variance): the replay of a whole generator is one call.  The jobs of a launch run concurrently: no two jobs among
+ * jobs[64k .. 64k+63] may name the same moving_mean / moving_var (refused); a layer whose averages move twice takes
+ * two calls. */
 typedef struct {
     float* moving_mean;
     float* moving_var;

@@ -403,8 +403,8 @@ class CycleGAN(object):
         fake_A = self.G(tp, tp.const(b), "generatorB2A").v
         return fake_A, fake_B
 
-    def g_loss(self, tp, real_data, which):
-        """cyclegan.py:56-68"""
+    def g_loss(self, tp, real_data, which, terms=None):
+        """cyclegan.py:56-68.  `terms`, a dict, receives the GAN term and the two weighted cycle terms."""
         a, b = self.split(real_data)
         ra, rb = tp.const(a), tp.const(b)
         fake_B = self.G(tp, ra, "generatorA2B")
@@ -417,38 +417,45 @@ class CycleGAN(object):
             gan = self.criterionGAN(tp, self.D(tp, fake_A, "discriminatorA"), 1.0)
         cyc_a = A.scale(tp, A.l1_mean(tp, ra, fake_A_), self.L1_lambda)
         cyc_b = A.scale(tp, A.l1_mean(tp, rb, fake_B_), self.L1_lambda)
+        if terms is not None:
+            terms['gan'], terms['cyc_a'], terms['cyc_b'] = float(gan.v), float(cyc_a.v), float(cyc_b.v)
         return A.add(tp, A.add(tp, gan, cyc_a), cyc_b)
 
-    def d_loss(self, tp, real, fake_sample, name):
-        """cyclegan.py:76-85"""
+    def d_loss(self, tp, real, fake_sample, name, terms=None):
+        """cyclegan.py:76-85.  `terms`, a dict, receives the two halves (each already divided by 2)."""
         l_real = self.criterionGAN(tp, self.D(tp, tp.const(real), name), 1.0)
         l_fake = self.criterionGAN(tp, self.D(tp, tp.const(fake_sample), name), 0.0)
+        if terms is not None:
+            terms['real'], terms['fake'] = 0.5 * float(l_real.v), 0.5 * float(l_fake.v)
         return A.scale(tp, A.add(tp, l_real, l_fake), 0.5)
 
-    def train_iteration(self, real_data):
-        """cyclegan.py:159-180: five sequential runs."""
+    def train_iteration(self, real_data, detail=None):
+        """cyclegan.py:159-180: five sequential runs.  `detail`, a dict, receives the ten loss terms
+        (db_loss_real ... g_b2a_cyc_b) and, under 'grads', each optimiser group's gradients by name."""
         a, b = self.split(real_data)
         fake_A, fake_B = self.forward_fakes(real_data)
         fake_A, fake_B = self.pool([fake_A, fake_B])
         out = {}
-        tp = A.Tape(self.st)
-        l = self.d_loss(tp, b, fake_B, "discriminatorB")
-        tp.backward(l)
-        self.db_adam.step(tp.grads(self.db_vars))
-        out['db_loss'] = float(l.v)
-        tp = A.Tape(self.st)
-        l = self.g_loss(tp, real_data, 'a2b')
-        tp.backward(l)
-        self.ga2b_adam.step(tp.grads(self.g_vars_a2b))
-        out['g_loss_a2b'] = float(l.v)
-        tp = A.Tape(self.st)
-        l = self.d_loss(tp, a, fake_A, "discriminatorA")
-        tp.backward(l)
-        self.da_adam.step(tp.grads(self.da_vars))
-        out['da_loss'] = float(l.v)
-        tp = A.Tape(self.st)
-        l = self.g_loss(tp, real_data, 'b2a')
-        tp.backward(l)
-        self.gb2a_adam.step(tp.grads(self.g_vars_b2a))
-        out['g_loss_b2a'] = float(l.v)
+        grads = {}
+
+        def run(key, loss_fn, names, adam, prefix):
+            tp = A.Tape(self.st)
+            terms = {}
+            l = loss_fn(tp, terms)
+            tp.backward(l)
+            grads[key] = tp.grads(names)
+            adam.step(grads[key])
+            if detail is not None:
+                detail.update({prefix + k: v for k, v in terms.items()})
+            return float(l.v)
+        out['db_loss'] = run('db', lambda tp, t: self.d_loss(tp, b, fake_B, "discriminatorB", t),
+                             self.db_vars, self.db_adam, 'db_loss_')
+        out['g_loss_a2b'] = run('g_a2b', lambda tp, t: self.g_loss(tp, real_data, 'a2b', t),
+                                self.g_vars_a2b, self.ga2b_adam, 'g_a2b_')
+        out['da_loss'] = run('da', lambda tp, t: self.d_loss(tp, a, fake_A, "discriminatorA", t),
+                             self.da_vars, self.da_adam, 'da_loss_')
+        out['g_loss_b2a'] = run('g_b2a', lambda tp, t: self.g_loss(tp, real_data, 'b2a', t),
+                                self.g_vars_b2a, self.gb2a_adam, 'g_b2a_')
+        if detail is not None:
+            detail['grads'] = grads
         return out

@@ -33,6 +33,23 @@ def test_host_side_argument_checks_need_no_gpu():
     assert _lib.lib.gan_linear_workspace_bytes(64, 100, 8192) >= 0
 
 
+def test_reflect_input_gradient_refuses_geometries_its_fold_is_not_the_adjoint_of():
+    """gan_conv2d_dgrad_reflect folds about a border of pt pixels on every side: only a filter that covers the
+    reflect-padded image exactly (tf.pad by p + VALID, cyclegan_module.py:102-110) makes that the adjoint of
+    gan_conv2d_fwd_reflect.  Other geometries are refused before any launch (fake non-null pointers, no GPU)."""
+    import ctypes
+    from gan_amd import _lib as L
+    fake = ctypes.c_void_p(256)
+    ok = L.conv_geom(1, 16, 16, 8, 16, 16, 8, 3, 3, 1, 1, 1, 1)       # 3x3 stride 1, pad 1 each side: 14 + 3 == 16 + 2 ... exact
+    assert (ok.hs - 1) * ok.sh + ok.kh == ok.hb + 2 * ok.pt
+    assert L.lib.gan_conv2d_dgrad_reflect_workspace_bytes(ctypes.byref(ok)) > 0
+    for bad in (L.conv_geom(1, 16, 16, 8, 8, 8, 8, 5, 5, 2, 2, 1, 1),     # TF SAME split (1, 2): one more pixel behind
+                L.conv_geom(1, 16, 16, 8, 8, 8, 8, 3, 3, 2, 2, 0, 0),     # TF SAME split (0, 1)
+                L.conv_geom(1, 16, 16, 8, 15, 15, 8, 3, 3, 1, 1, 1, 1)):  # small side one short of covering the padding
+        rc = L.lib.gan_conv2d_dgrad_reflect(ctypes.byref(bad), fake, fake, fake, fake, 1 << 30, None)
+        assert rc != 0 and b"cover the reflect-padded image exactly" in L.lib.gan_last_error(), L.lib.gan_last_error()
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "gan_amd")
     for dirpath, _, files in os.walk(pkg):

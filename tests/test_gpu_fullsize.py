@@ -107,35 +107,46 @@ def test_mnist_conditional_dcgan_full_size_against_oracle():
             assert abs(got[k_] - want[k_]) <= 2e-3 * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
 
 
-class _lrelu_recorder(object):
-    """Records the output of every leaky-relu the discriminator applies on the GPU side (the one fused into
-    d_h0_conv's epilogue and the ones fused into the batch norms), in call order."""
+class _act_recorder(object):
+    """Records the output of every activation of the given kinds that the model applies on the GPU side (the
+    leaky-relu fused into d_h0_conv's epilogue, the relus / leaky-relus fused into the batch norms), in call order,
+    as (kind, tensor)."""
+
+    def __init__(self, kinds=('lrelu',)):
+        self.kinds = kinds
 
     def __enter__(self):
         import gan_amd.dcgan as D
         from gan_amd import ops
-        self.outputs = []
+        self.records = []
         self.saved = (D.conv2d, ops.batch_norm.__call__)
-        rec = self.outputs
+        rec, kinds = self.records, self.kinds
 
         def conv2d(x, *a, **k):
             y = self.saved[0](x, *a, **k)
-            if k.get('act') == 'lrelu':
-                rec.append(y)
+            if k.get('act') in kinds:
+                rec.append((k['act'], y))
             return y
 
         def bn_call(bn, x, *a, **k):
             y = self.saved[1](bn, x, *a, **k)
-            if k.get('act') == 'lrelu':
-                rec.append(y)
+            if k.get('act') in kinds:
+                rec.append((k['act'], y))
             return y
         D.conv2d, ops.batch_norm.__call__ = conv2d, bn_call
         return self
+
+    @property
+    def outputs(self):
+        return [t for _, t in self.records]
 
     def __exit__(self, *exc):
         import gan_amd.dcgan as D
         from gan_amd import ops
         D.conv2d, ops.batch_norm.__call__ = self.saved
+
+
+_lrelu_recorder = _act_recorder
 
 
 def test_dcgan64_full_size_against_oracle():
@@ -198,13 +209,17 @@ def test_dcgan64_full_size_against_oracle():
     assert calls[0] == 8
     tp.backward(A.add(tp, lr_, lf_))
     want_g = tp.grads(ref.d_vars)
-    print("units masked at the leaky-relu kink: %d of %d" % (masked[0], sum(a.size for a in gpu_act)))
+    total_units = sum(a.size for a in gpu_act)
+    print("units masked at the leaky-relu kink: %d of %d" % (masked[0], total_units))
+    # the mask must stay a handful of units: a wrong pre-activation could otherwise hide behind it
+    assert masked[0] < 1e-3 * total_units
     check_group_grads(gpu.d_group, want_g, tol=3e-4)
     top = ('d_h3_lin/Matrix', 'd_h3_lin/bias', 'd_bn3/beta', 'd_bn3/gamma')
     for v in gpu.d_group.variables:
         if v.name.split('/', 1)[1] in top:
             from gpu_util import assert_close
             assert_close(host(v.grad), want_g[v.name], "grad " + v.name, tol=1e-5, elementwise=False)
+    _check_g_update_gradients(ref, gpu, z)
     for it in range(2):
         want = ref.train_iteration(im.astype(np.float64), z.astype(np.float64))
         out = gpu.train_iteration(dev(im), dev(z))
@@ -218,6 +233,60 @@ def test_dcgan64_full_size_against_oracle():
             assert abs(got[k_] - want[k_]) <= tol * max(1.0, abs(want[k_])), (it, k_, got[k_], want[k_])
         im = rng.uniform(-1, 1, (64, 64, 64, 3)).astype(np.float32)
         z = rng.uniform(-1, 1, (64, 100)).astype(np.float32)
+
+
+def _check_g_update_gradients(ref, gpu, z):
+    """The G update's gradients at the benchmarked size (dcgan.py:237-247: backward through D into G -- the
+    deconvolutions' input and weight gradients, the gated tanh) against the float64 oracle, at the initial weights.
+    The relu units of the generator and the leaky-relu units of the discriminator pass that sit within 2e-5 of
+    their kink in float64 take, in the oracle's backward pass, the branch the GPU took (read from its activations),
+    as in the D update's comparison; their number is printed and bounded.  Every generator gradient to 3e-4
+    (max-norm); biases in front of a batch norm are noise on both sides."""
+    from oracle import autodiff as A
+    from oracle import tf_ops as T
+    from gpu_util import assert_close, check_group_grads, dev, host
+    with _act_recorder(('relu', 'lrelu')) as rec:
+        g_loss = gpu.g_grads(dev(z))
+    torch.cuda.synchronize()
+    kinds = [k for k, _ in rec.records]
+    assert kinds == ['relu'] * 4 + ['lrelu'] * 4, kinds          # g_bn0..3, then h0..h3 of D(G(z))
+    gpu_act = {'relu': [host(t) for k, t in rec.records if k == 'relu'],
+               'lrelu': [host(t) for k, t in rec.records if k == 'lrelu']}
+    margin, calls, masked = 2e-5, {'relu': 0, 'lrelu': 0}, [0]
+    plain = (A.relu, A.lrelu)
+
+    def follow(kind, x):
+        act = gpu_act[kind][calls[kind]]
+        calls[kind] += 1
+        assert act.shape == x.v.shape
+        near = np.abs(x.v) < margin
+        masked[0] += int(near.sum())
+        return near, act
+
+    def relu(tp, x):
+        near, act = follow('relu', x)
+        on = np.where(near, act > 0, x.v > 0)
+        return tp.op(T.relu(x.v), [x], lambda g: x.accumulate(np.where(on, g, 0.0)))
+
+    def lrelu(tp, x, leak=0.2):
+        near, act = follow('lrelu', x)
+        upper = np.where(near, act >= 0, x.v >= 0)
+        return tp.op(T.lrelu(x.v, leak), [x], lambda g: x.accumulate(np.where(upper, g, x.v.dtype.type(leak) * g)))
+    tp = A.Tape(ref.st)
+    A.relu, A.lrelu = relu, lrelu
+    try:
+        G = ref.generator(tp, tp.const(z.astype(np.float64)))
+        want_loss = A.sigmoid_ce_mean(tp, ref.discriminator(tp, G), 1.0)
+    finally:
+        A.relu, A.lrelu = plain
+    assert calls == {'relu': 4, 'lrelu': 4}
+    tp.backward(want_loss)
+    want_g = tp.grads(ref.g_vars)
+    total_units = sum(a.size for v in gpu_act.values() for a in v)
+    print("G update: units masked at a relu / leaky-relu kink: %d of %d" % (masked[0], total_units))
+    assert masked[0] < 1e-3 * total_units
+    assert_close([float(g_loss)], [float(want_loss.v)], "g_loss at the initial weights", tol=1e-5)
+    check_group_grads(gpu.g_group, want_g, tol=3e-4)
 
 
 def test_dcgan64_full_size_loss_trajectory_200_steps():
@@ -336,3 +405,141 @@ def test_cyclegan_full_size_iteration():
             assert np.isfinite(a[k]) and a[k] == b[k], k
     # cycle terms: L1_lambda * mean|x - G(G(x))| of U(-1,1) images against a tanh output is O(lambda * 0.5)
     assert 1.0 < runs[0][0]['g_loss_a2b'] < 30.0 and 0.0 < runs[0][0]['db_loss'] < 5.0
+
+
+def _golden(module):
+    import importlib
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    try:
+        return importlib.import_module(module), here
+    finally:
+        sys.path.remove(here)
+
+
+def test_text2image_full_size_losses_against_the_float64_oracle_fixture():
+    """BASELINE config 3 of the hot path, Text2Image GAN-CLS at 64x64, batch 64 (models/text2image.py:73-128,
+    243-279): 12 iterations (1 D update on real / wrong / fake + 2 G updates each) against the committed
+    float64-oracle fixture tests/golden/t2i64_traj.npz (generator script alongside: seeds only, the weights and
+    the inputs are drawn again here).  Stated tolerance, as for DCGAN-64: every loss of the first iteration within
+    1e-3 (relative, losses below 1 absolute); afterwards the running maximum of |loss - float64 oracle| stays within
+    4x that of the oracle run in float32 (+ 2e-3), the yardstick for what float32 rounding does to this
+    trajectory (0.004 after 1 iteration, 0.07 after 6, 0.4 after 7 for the float32 ORACLE)."""
+    import os
+    from gan_amd.main import build_parser
+    from gan_amd.text2image import Text2Image
+    from gpu_util import dev
+    M, here = _golden("make_fullsize_pins")
+    gold = np.load(os.path.join(here, "t2i64_traj.npz"))
+    assert int(gold['weight_seed']) == M.T2I_WEIGHT_SEED and int(gold['data_seed']) == M.T2I_DATA_SEED
+    assert [str(c) for c in gold['columns']] == list(M.T2I_COLUMNS)
+    want, yard = gold['losses'], gold['losses_f32']
+    st, _ = M.t2i_oracle()
+    o = build_parser().parse_args("--dataset flowers --input_height 64 --model Text2Image --textEncoder DSSJE".split())
+    gpu = Text2Image(None, o)
+    assert list(gpu.store.vars) == list(st.values)
+    gpu.store.load_state_dict(st.values)
+    rng = np.random.default_rng(M.T2I_DATA_SEED)
+    outs = []
+    for it in range(want.shape[0]):
+        outs.append(gpu.train_iteration(*[dev(a) for a in M.t2i_draw(rng)]))
+    torch.cuda.synchronize()
+    got = np.array([[float(o_[k]) for k in M.T2I_COLUMNS] for o_ in outs])
+    assert np.isfinite(got).all()
+    first = np.abs(got[0] - want[0]) / np.maximum(1.0, np.abs(want[0]))
+    dev_gpu = np.maximum.accumulate(np.abs(got - want).max(axis=1))
+    dev_f32 = np.maximum.accumulate(np.abs(yard - want).max(axis=1))
+    print("Text2Image 64x64: first iteration's relative loss deviations %s; running max |loss - float64 oracle| at "
+          "iterations 1 / 3 / 6 / 12: gpu %s, float32 numpy oracle %s"
+          % (np.array2string(first, precision=2), np.round(dev_gpu[[0, 2, 5, 11]], 4), np.round(dev_f32[[0, 2, 5, 11]], 4)))
+    assert (first <= 1e-3).all(), first
+    assert (dev_gpu <= 4 * dev_f32 + 2e-3).all(), np.nonzero(dev_gpu > 4 * dev_f32 + 2e-3)[0][:5]
+
+
+def test_cyclegan_full_size_against_the_float64_oracle_fixture():
+    """CycleGAN at 256x256, batch 1, gf_dim = df_dim = 64 (models/cyclegan.py:47-116,159-180) against the committed
+    float64-oracle fixture tests/golden/cyclegan256_pin.npz.
+    (A) Each of the four updates evaluated at the initial weights: its loss terms to 1e-4 and, for every variable, a
+    checksum of its gradient -- L2 norm and projection onto a seeded +-1 vector -- within max(5e-4, 4x the float32
+    oracle's deviation) of the variable's gradient norm: the generators are ~50 normalised layers deep with relu
+    kinks among 4M units per layer, and the float32 oracle's own deviation from float64 is the yardstick for
+    what float32 arithmetic can deliver there.  Biases in front of a batch norm (zero true gradient) must stay tiny.
+    (B) Two iterations of the schedule: all ten loss terms, the first iteration's within 1e-3 (relative, terms
+    below 1 absolute) and 4x the yardstick, the second's within 4x the yardstick + 2e-3."""
+    import os
+    from gan_amd.cyclegan import CycleGAN
+    from gan_amd.main import build_parser
+    from gpu_util import dev, host
+    M, here = _golden("make_fullsize_pins")
+    gold = np.load(os.path.join(here, "cyclegan256_pin.npz"))
+    assert int(gold['weight_seed']) == M.CYC_WEIGHT_SEED and int(gold['data_seed']) == M.CYC_DATA_SEED
+    assert int(gold['proj_seed']) == M.CYC_PROJ_SEED and [str(c) for c in gold['columns']] == list(M.CYC_COLUMNS)
+    st, _ = M.cyc_oracle()
+    initial = {n: v.copy() for n, v in st.values.items()}
+    o = build_parser().parse_args("--model CycleGAN --batch_size 1 --dataset horse2zebra".split())
+    assert o.max_size == 50 and o.fine_size == 256
+    m = CycleGAN(None, o)
+    assert list(m.store.vars) == list(st.values)
+    rng = np.random.default_rng(M.CYC_DATA_SEED)
+    real = dev(M.cyc_draw(rng))
+    real_A, real_B = m.split(real)
+    # ---- (A) the four updates, each from the initial weights
+    m.store.load_state_dict(initial)
+    fake_A, fake_B = m.forward_fakes(real)
+    runs = (('db', lambda: m.d_update('B', real_B, fake_B), ('db_loss_real', 'db_loss_fake')),
+            ('g_a2b', lambda: m.g_update('a2b', real), ('g_a2b_gan', 'g_a2b_cyc_a', 'g_a2b_cyc_b')),
+            ('da', lambda: m.d_update('A', real_A, fake_A), ('da_loss_real', 'da_loss_fake')),
+            ('g_b2a', lambda: m.g_update('b2a', real), ('g_b2a_gan', 'g_b2a_cyc_a', 'g_b2a_cyc_b')))
+    col = {c: i for i, c in enumerate(M.CYC_COLUMNS)}
+    worst = {}
+    for key, run, terms in runs:
+        m.store.load_state_dict(initial)
+        vals = run()
+        torch.cuda.synchronize()
+        for t, v in zip(terms, vals):
+            w = float(gold['init_losses'][col[t]])
+            assert abs(float(v) - w) <= 1e-4 * max(1.0, abs(w)), (t, float(v), w)
+        names = [str(n) for n in gold[key + '_names']]
+        grads = {v.name: host(v.grad).astype(np.float64) for v in m.optims[key].group.variables}
+        assert list(grads) == names
+        n64, p64 = gold[key + '_norm'], gold[key + '_proj']
+        n32, p32 = gold[key + '_norm_f32'], gold[key + '_proj_f32']
+        biggest = float(n64.max())
+        bad = []
+        w_gpu = w_f32 = 0.0
+        for i, name in enumerate(names):
+            g = grads[name]
+            nrm = float(np.sqrt((g * g).sum()))
+            if n64[i] < 1e-5 * biggest:                    # a bias in front of a batch norm: rounding noise on both sides
+                assert nrm < 1e-3 * biggest, (name, nrm, biggest)
+                continue
+            prj = float((g * M.cyc_projection(name, g.shape)).sum())
+            e_gpu = max(abs(nrm - n64[i]), abs(prj - p64[i])) / n64[i]
+            e_f32 = max(abs(n32[i] - n64[i]), abs(p32[i] - p64[i])) / n64[i]
+            w_gpu, w_f32 = max(w_gpu, e_gpu), max(w_f32, e_f32)
+            if e_gpu > max(5e-4, 4 * e_f32):
+                bad.append((name, e_gpu, e_f32))
+        worst[key] = (w_gpu, w_f32)
+        assert not bad, bad
+    print("CycleGAN 256x256 gradient checksums at the initial weights, worst deviation / gradient norm per group "
+          "(gpu, float32 numpy oracle): %s" % {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in worst.items()})
+    # ---- (B) the schedule
+    m = CycleGAN(None, o)
+    m.store.load_state_dict(initial)
+    want, yard = gold['losses'], gold['losses_f32']
+    rng = np.random.default_rng(M.CYC_DATA_SEED)
+    for it in range(want.shape[0]):
+        out = m.train_iteration(dev(M.cyc_draw(rng)))
+        torch.cuda.synchronize()
+        got = np.array([float(out[c]) for c in M.CYC_COLUMNS])
+        d_gpu, d_f32 = np.abs(got - want[it]), np.abs(yard[it] - want[it])
+        print("CycleGAN 256x256 iteration %d: max |term - float64 oracle| gpu %.2e, float32 numpy oracle %.2e"
+              % (it, d_gpu.max(), d_f32.max()))
+        if it == 0:
+            assert (d_gpu <= 1e-3 * np.maximum(1.0, np.abs(want[it]))).all(), (got, want[it])
+            assert (d_gpu <= 4 * d_f32 + 1e-4).all(), (d_gpu, d_f32)
+        else:
+            assert (d_gpu <= 4 * d_f32.max() + 2e-3).all(), (d_gpu, d_f32)
+    assert m.pool.num_img == 2 and all(opt.steps_taken == 2 for opt in m.optims.values())

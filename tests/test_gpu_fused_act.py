@@ -212,3 +212,35 @@ def test_reflect_padding_folded_into_the_gather(case):
     assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l1))
     assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
     assert float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx1.abs().max())
+
+
+@pytest.mark.parametrize("gated_first", [True, False])
+def test_fused_activation_output_with_two_consumers_is_refused(gated_first):
+    """The output of conv2d(.., act=) may feed ONE differentiable consumer chain.  With a gated consumer (a conv2d that
+    applies the activation's derivative while it stores its input gradient) and a second consumer, the gradient
+    that reaches the producing layer is a sum of one term that went through the derivative and one that did not:
+    the backward pass must raise, whichever of the two gradients autograd sees first (when the gated one comes first
+    and autograd holds its only reference, the second is added into it IN PLACE: same address, moved version)."""
+    from gan_amd import ops, variables as V
+    from gan_amd.optim import AdamOptimizer
+    store = V.VariableStore(device='cuda', seed=4)
+    x = torch.randn(2, 8, 8, 8, device='cuda')
+    with V.use_store(store):
+        def net(inp):
+            y = ops.conv2d(inp, 8, 3, 3, 1, 1, name='p', act='lrelu')
+            if gated_first:          # the consumer created LAST runs its backward FIRST
+                b = ops.mse_const_mean(y, 0.0)
+                a = ops.mse_const_mean(ops.conv2d(y, 8, 3, 3, 1, 1, name='c'), 0.1)
+            else:
+                a = ops.mse_const_mean(ops.conv2d(y, 8, 3, 3, 1, 1, name='c'), 0.1)
+                b = ops.mse_const_mean(y, 0.0)
+            return [a, b]
+        with torch.no_grad():
+            net(x)
+        group = store.pack('n', store.trainable_variables())
+        opt = AdamOptimizer(1e-3, beta1=0.5).attach(group)
+        opt.begin()
+        losses = net(x.clone().requires_grad_(True))
+        with pytest.raises(RuntimeError, match="feeds a gated consumer AND something else"):
+            ops.backward(losses)
+        torch.cuda.synchronize()
