@@ -72,7 +72,7 @@ class ContractionTimer(object):
             if is_conv:
                 g = args[0]._obj
                 flops = conv_flops(g)
-                shape = (g.n, g.hb, g.wb, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, g.sh)
+                shape = (g.n, g.hb, g.wb, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl)
             else:
                 flops = 2.0 * args[0] * args[1] * args[2]
                 shape = tuple(args[:3])
@@ -175,18 +175,64 @@ def cpu_baseline(iters):
                       "CPU restatement, not TensorFlow" % iters}
 
 
-def committed_traffic(skip):
+PLANS_FILE = os.path.join(ROOT, "profiles", "r03_plans.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+
+# contraction mode (0 forward, 1 transposed, 2 weight gradient) behind each C-ABI entry point
+ENTRY_MODE = {"gan_conv2d_fwd": 0, "gan_conv2d_dgrad": 1, "gan_conv2d_wgrad": 2,
+              "gan_deconv2d_fwd": 1, "gan_deconv2d_dgrad": 0, "gan_deconv2d_wgrad": 2,
+              "gan_conv2d_fwd_act": 0, "gan_deconv2d_fwd_act": 1, "gan_conv2d_dgrad_gated": 1, "gan_deconv2d_dgrad_gated": 0,
+              "gan_conv2d_fwd_reflect": 0, "gan_conv2d_wgrad_reflect": 2, "gan_conv2d_dgrad_reflect": 1,
+              "gan_linear_fwd": 0, "gan_linear_dgrad": 1, "gan_linear_wgrad": 2}
+
+
+def source_sha16():
+    """Hash of the library's sources (gan_amd/csrc/*.hip, *.h, include/gan_hip.h): which kernels a number belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "gan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gan_amd", "csrc", "*.h")))
+    for f in files + [os.path.join(ROOT, "include", "gan_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def plan_set_sha16(L, calls):
+    """Hash of the contraction plans (tile configuration, split-K factor, thin path) the library runs for the given
+    calls [(entry point name, geometry tuple)], asked from the library itself: two runs with the same hash launch
+    the same kernels with the same split-K summation order."""
+    import ctypes
+    import hashlib
+    plans = set()
+    for name, shape in calls:
+        g = L.ConvGeom()
+        if name.startswith("gan_linear"):
+            L.check(L.lib.gan_linear_as_conv_geom(shape[0], shape[1], shape[2], ctypes.byref(g)))
+        else:
+            g = L.ConvGeom(*shape)
+        c, sp, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.check(L.lib.gan_conv_plan_get(ENTRY_MODE[name], ctypes.byref(g), ctypes.byref(c), ctypes.byref(sp), ctypes.byref(thin)))
+        plans.add((ENTRY_MODE[name],) + tuple(g.key()) + (c.value, sp.value, thin.value))
+    return hashlib.sha1(json.dumps(sorted(plans)).encode()).hexdigest()[:16]
+
+
+def committed_traffic(skip, plans_sha, src_sha):
     """HBM-side bytes of the contraction launches of one step, from the committed rocprofv3 counter passes
-    (profiles/r02_traffic.json: FETCH_SIZE with the gfx950 doubling + WRITE_SIZE, summed over the same
-    launches `roofline.achieved` is timed on).  Counters cannot be read from inside this process, so the figure
-    is the committed one, valid for the default arithmetic at batch 64 only."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if skip or not os.path.exists(path):
+    (FETCH_SIZE with the gfx950 doubling + WRITE_SIZE, summed over the same launches `roofline.achieved` is timed
+    on).  Counters cannot be read from inside this process, so the figure is a committed one; it is attached only
+    when the committed passes ran the same plans (plan-set hash) on the same library sources (source hash) as this
+    run, and is null with the reason otherwise."""
+    if skip or not os.path.exists(TRAFFIC_FILE):
         return None, "no committed counter pass for this configuration"
-    t = json.load(open(path))
+    t = json.load(open(TRAFFIC_FILE))
+    if t.get("plans_sha16") != plans_sha or t.get("source_sha16") != src_sha:
+        return None, ("the committed counter passes (profiles/r03_traffic.md) ran plan set %s on library sources %s; this run "
+                      "has plan set %s on sources %s" % (t.get("plans_sha16"), t.get("source_sha16"), plans_sha, src_sha))
     return (int(t["read_bytes_per_iteration"] + t["written_bytes_per_iteration"]),
-            "profiles/r02_traffic.md (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE over tools/traffic_probe.py): "
-            "%.2f GB read + %.2f GB written per step" % (t["read_bytes_per_iteration"] / 1e9, t["written_bytes_per_iteration"] / 1e9))
+            "profiles/r03_traffic.md (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE over tools/traffic_probe.py, same plan set "
+            "and library sources as this run): %.2f GB read + %.2f GB written per step"
+            % (t["read_bytes_per_iteration"] / 1e9, t["written_bytes_per_iteration"] / 1e9))
 
 
 def exact_f32_step_ms(model, pool, _lib, steps=10):
@@ -251,6 +297,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
+    ap.add_argument("--plans", default=PLANS_FILE,
+                    help="JSON file of pinned contraction plans (gan_amd.autotune.save): loaded when it exists, so that every "
+                         "run launches the same kernels; geometries it does not hold are tuned at start-up")
+    ap.add_argument("--retune", action="store_true", help="ignore --plans and time the candidate plans at start-up")
+    ap.add_argument("--save-plans", default=None, help="write the plans this run ended up with to this file")
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--dp-whole-graph", action="store_true",
                     help="data parallel: capture the all-reduces INTO one HIP graph instead of cutting the iteration "
@@ -324,6 +375,10 @@ def main():
     if args.exact_f32:
         _lib.lib.gan_set_exact_f32(1)
     autotune.enable(not args.no_autotune)   # plans are tuned during model construction (eager), before capture
+    plans_loaded = False
+    if not args.no_autotune and not args.retune and not args.exact_f32 and BATCH == nominal_batch and os.path.exists(args.plans):
+        autotune.load(args.plans)
+        plans_loaded = True
 
     model = DCGAN(None, dcgan64_opts(seed=0), world_size=world, process_group=pg, load_data=False)
     # synthetic CelebA-shaped data, per-rank seed, resident in HBM before the timed region
@@ -377,7 +432,11 @@ def main():
                   "on the buffers of a captured iteration" % seq_calls)
     achieved = flops / (ms * 1e-3) / 1e12
     exact = bool(_lib.lib.gan_get_exact_f32())
-    traffic, traffic_note = committed_traffic(exact or BATCH != nominal_batch or alg_bytes is None)
+    plans_sha = plan_set_sha16(_lib, sorted(set((name, shape) for name, shape, _, _, _ in tm.records)))
+    src_sha = source_sha16()
+    if args.save_plans and rank == 0:
+        autotune.save(args.save_plans)
+    traffic, traffic_note = committed_traffic(exact or BATCH != nominal_batch or alg_bytes is None, plans_sha, src_sha)
     # `achieved` counts the ALGORITHMIC fp32 FLOP of the convolutions.  The default arithmetic forms every
     # fp32 product from six bf16 x bf16 part products on the bf16 matrix pipe, so the MFMA ceiling for
     # algorithmic FLOP is the bf16 peak / 6; with --exact-f32 it is the fp32 MFMA peak.
@@ -417,7 +476,10 @@ def main():
                                                                % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")),
                        "schedule": "the first G update reuses the D update's generator pass (same z, same weights; "
                                    "trained weights identical to re-running it, batch-norm moving variances equal to float32 rounding)",
-                       "contraction_plans": "heuristic" if args.no_autotune else "autotuned at start-up"},
+                       "contraction_plans": ("heuristic" if args.no_autotune else
+                                             "pinned from %s" % os.path.relpath(args.plans, ROOT) if plans_loaded else
+                                             "autotuned at start-up"),
+                       "plans_sha16": plans_sha, "library_source_sha16": src_sha},
             "roofline": roof,
             "mfma_util_step": round(roof["flop_per_step"] * 1e9 / (ms_per_step * 1e-3) / 1e12 / peak, 4),
             "losses_last_step": {k: round(v, 5) for k, v in losses.items()},

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--plans", default=None, help="JSON file of tuned plans: written if absent, pinned if present "
                     "(so that the two counter passes run the same kernels)")
+    ap.add_argument("--meta", default=None, help="write {plans_sha16, source_sha16} of the launches here (JSON)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     mark = torch.zeros(4, device='cuda')
@@ -91,6 +92,21 @@ def main():
     marker(mark)
     torch.cuda.synchronize()
     flops = sum(r[2] for r in rec.records)
+    # which plans and which library sources these launches belong to (bench.py attaches the traffic figure only to runs
+    # with the same two hashes)
+    calls = []
+    for fn, a, _, _ in rec.records:
+        name = fn.__name__ if hasattr(fn, "__name__") else str(fn)
+        if name.startswith("gan_linear"):
+            calls.append((name, tuple(int(v) for v in a[:3])))
+        else:
+            calls.append((name, tuple(a[0]._obj.key())))
+    meta = {"plans_sha16": bench.plan_set_sha16(_lib, sorted(set(calls))), "source_sha16": bench.source_sha16(),
+            "plans_file": args.plans and os.path.relpath(os.path.abspath(args.plans), bench.ROOT), "replays": args.replays}
+    if args.meta:
+        import json
+        json.dump(meta, open(args.meta, "w"))
+    print("plan set %s, library sources %s" % (meta["plans_sha16"], meta["source_sha16"]), flush=True)
     print("contraction calls per iteration: %d, nominal GFLOP per iteration: %.2f, replays: %d"
           % (len(rec.records), flops / 1e9, args.replays), flush=True)
 

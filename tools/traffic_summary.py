@@ -2,7 +2,7 @@
 """Summarise the `rocprofv3 --pmc` passes over tools/traffic_probe.py into HBM-side bytes per iteration of the
 contraction family.
 
-    python tools/traffic_summary.py <fetch_pass_dir> <write_pass_dir> <replays> <out.md> <out.json>
+    python tools/traffic_summary.py <fetch_pass_dir> <write_pass_dir> <replays> <out.md> <out.json> [<meta.json of traffic_probe.py --meta>]
 
 Reads: FETCH_SIZE (KiB) from the first pass, WRITE_SIZE (KiB) and TCC_WRITE_sum (write requests arriving at L2)
 from the second.  Corrections: FETCH_SIZE counts a 128-byte request as 64 bytes for 16-byte-per-lane streaming
@@ -52,6 +52,7 @@ def family(name):
 
 def main():
     fetch_dir, write_dir, replays, out_md, out_json = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    meta = json.load(open(sys.argv[6])) if len(sys.argv) > 6 else {}
     fr, wr = load(fetch_dir), load(write_dir)
     (fc0, fc1), (fk0, fk1) = regions(fr)
     (wc0, wc1), (wk0, wk1) = regions(wr)
@@ -61,7 +62,8 @@ def main():
     gather_cal = [r for r in fcal[2:] if "igemm" in r["name"]]      # the two 1x1 convolutions
     fetch_factor = cal_bytes[0] / (fcal[0]["c"]["FETCH_SIZE"] * 1024)
     bytes_per_wreq = cal_bytes[0] / wcal[0]["c"]["TCC_WRITE_sum"]
-    lines = ["# HBM-side traffic of the contraction family, DCGAN-64 batch 64 (round 2)", "",
+    lines = ["# HBM-side traffic of the contraction family, DCGAN-64 batch 64", "",
+             "Plan set `%s` (%s), library sources `%s`." % (meta.get("plans_sha16"), meta.get("plans_file"), meta.get("source_sha16")), "",
              "`rocprofv3 --pmc FETCH_SIZE -- python3 tools/traffic_probe.py` and, in a run of its own, "
              "`rocprofv3 --pmc WRITE_SIZE TCC_WRITE_sum -- python3 tools/traffic_probe.py`; summarised by "
              "`tools/traffic_summary.py` over %d replays of the graph that holds only the contraction calls of one "
@@ -106,7 +108,8 @@ def main():
     lines += ["", "Contraction family per iteration: **%.1f MB read + %.1f MB written = %.1f MB** over %.1f launches."
               % (tot_r / 1e6, tot_w / 1e6, (tot_r + tot_w) / 1e6, n_launch / replays)]
     open(out_md, "w").write("\n".join(lines) + "\n")
-    json.dump({"read_bytes_per_iteration": tot_r, "written_bytes_per_iteration": tot_w,
+    json.dump({"plans_sha16": meta.get("plans_sha16"), "source_sha16": meta.get("source_sha16"),
+               "plans_file": meta.get("plans_file"), "read_bytes_per_iteration": tot_r, "written_bytes_per_iteration": tot_w,
                "launches_per_iteration": n_launch / replays, "fetch_factor_measured": fetch_factor,
                "bytes_per_write_request": bytes_per_wreq,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE TCC_WRITE_sum over tools/traffic_probe.py, tools/traffic_summary.py"},
