@@ -71,6 +71,7 @@ Knobs& knobs() {
         r.tile_order = env_int("GAN_HIP_TILE_ORDER", 0);
         r.rgb_gather = env_int("GAN_HIP_RGB_GATHER", 1);
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
+        r.no_carry = getenv("GAN_HIP_NO_CARRY") != nullptr;
         return r;
     }();
     return k;
@@ -528,6 +529,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
     else if (!strcmp(name, "tile_order")) k.tile_order = value;
     else if (!strcmp(name, "rgb_gather")) k.rgb_gather = value;
+    else if (!strcmp(name, "no_carry")) k.no_carry = value != 0;
     else return fail("gan_knob_set: unknown knob '%s'", name);
     return 0;
 }

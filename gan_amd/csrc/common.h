@@ -39,6 +39,7 @@ struct Knobs {
     int rgb_gather;       // GAN_HIP_RGB_GATHER: filter-row gather for 3-channel images: 1 FPROP and WGRAD, 2 WGRAD only, 0 off
     int tile_order;       // GAN_HIP_TILE_ORDER: 0 chosen per launch, 1 launch order, 2 by row tile, 3 by k range
     int exact_f32;      // GAN_HIP_EXACT_F32: default of gan_set_exact_f32
+    int no_carry;       // GAN_HIP_NO_CARRY: the last stage of a bias-gradient column sum never rides on a contraction launch
 };
 Knobs& knobs();
 

@@ -85,7 +85,12 @@ struct IgemmArgs {
     int row3_spr;  // > 0: filter-row gather of a 3-channel big image (igemm_split.h, ROW3), slices per filter row
     int grid_mt, grid_nt, grid_z;  // row tiles, column tiles, (parity classes x k splits) of the one-dimensional grid
     int xcd_order;                 // tile_of_workgroup: 0 / 3 launch order (k range / row tile fastest), 1 / 2 XCD-aware
+    // Workgroups beyond own_blocks carry the last stage of a bias-gradient column sum (its partial sums were left by
+    // a launch ahead of this one).
+    int own_blocks;
+    ColsumFinal tail;
 };
+
 
 // Which tile a workgroup computes.  The grid is one-dimensional.  The hardware hands workgroups to the 8 XCDs
 // round robin in launch order (position L runs on XCD L % 8) and every XCD has an L2 of its own, so tiles that
@@ -1328,13 +1333,20 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     a.grid_nt = pl.nt;
     a.grid_z = pl.splits * a.ncls;
     a.xcd_order = tile_order(mode, a, pl);
-    dim3 grid((unsigned)(pl.mt * pl.nt * pl.splits * a.ncls));
+    const long own_blocks = (long)pl.mt * pl.nt * pl.splits * a.ncls;
+    const bool split_kernel = pl.cfg >= kFirstSplitCfg;
+    // the last stage of a pending bias-gradient column sum rides on this launch when no reduction launch follows
+    const bool carry = split_kernel && job.blocks > 0 && pl.splits == 1 && !knobs().no_carry;
+    a.own_blocks = (int)own_blocks;
+    if (carry) a.tail = job;
+    dim3 grid((unsigned)(own_blocks + (carry ? job.blocks : 0)));
     switch (mode) {
         case MODE_FPROP: launch_cfg<MODE_FPROP>(a, pl, grid, s); break;
         case MODE_TPROP: launch_cfg<MODE_TPROP>(a, pl, grid, s); break;
         default: launch_cfg<MODE_WGRAD>(a, pl, grid, s); break;
     }
     if (int rc = check_launch(what)) return rc;
+    if (carry) *tail_done = 1;
     if (fold != nullptr) {
         launch_fold(static_cast<const float*>(ws), final_out, *fold, pl.splits, pl.out_elems, s);
         return check_launch(what);
@@ -1387,6 +1399,8 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.epi = no_epilogue();
     r.reflect = 0;
     r.row3_spr = 0;
+    r.own_blocks = 0x7fffffff;
+    r.tail = ColsumFinal{nullptr, nullptr, 0, 0, 0, 0};
     r.d_cb = make_fastdiv((unsigned)g.cb);
     r.d_cs = make_fastdiv((unsigned)g.cs);
     r.d_kw = make_fastdiv((unsigned)g.kw);

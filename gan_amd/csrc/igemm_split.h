@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     static_assert(KG == 1 || TM * TN * 16 * 256 * 4 <= KG * 2 * STAGE, "the accumulator hand-over must fit the staging buffers");
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[KG * 2 * STAGE];
 
+    if ((int)blockIdx.x >= p.own_blocks) {    // (uniform per workgroup) carried job: last stage of a bias-gradient column sum
+        if (threadIdx.x < 256) colsum_final_block(p.tail, (int)blockIdx.x - p.own_blocks);
+        return;
+    }
     const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
     unsigned char* const smem_raw = smem_all + kgrp * (2 * STAGE);
     const int tid = threadIdx.x & 255;

@@ -801,6 +801,45 @@ def test_bias_gradient_carried_by_the_slab_reduction_is_bit_identical(L, case, a
         torch.testing.assert_close(outs[0][3].double(), x.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("case", [(4, 16, 16, 64, 128, 5, 2), (3, 14, 16, 32, 80, 5, 2), (2, 17, 13, 16, 144, 3, 1),
+                                  (8, 8, 8, 256, 512, 5, 2)])
+@pytest.mark.parametrize("cfg", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_bias_gradient_carried_by_the_contraction_launch_is_bit_identical(L, case, cfg, accumulate):
+    """A weight gradient without split-K slabs has no reduction launch: the last stage of the bias gradient's column
+    sum then rides on extra workgroups of the contraction launch itself (256- and 512-thread workgroups alike)
+    instead of being a launch of its own (knob no_carry).  Same numbers either way, for conv and transposed conv,
+    overwriting or accumulating."""
+    from gpu_util import geom_for
+    n, h, w, cb, cs, k, s = case
+    g = geom_for(n, h, w, cb, cs, k, s, 'SAME')
+    gp = ctypes.byref(g)
+    torch.manual_seed(17)
+    x = torch.randn(n, h, w, cb, device='cuda')
+    dy = torch.randn(n, g.hs, g.ws, cs, device='cuda')
+    L.knob_set("force_cfg", cfg)
+    L.knob_set("force_splits", 1)
+    outs = []
+    for no_carry in (0, 1, 0):
+        L.knob_set("no_carry", no_carry)
+        torch.manual_seed(5)
+        dw, db = torch.randn(k, k, cb, cs, device='cuda'), torch.randn(cs, device='cuda')      # accumulated onto
+        dwt, dbt = torch.randn(k, k, cb, cs, device='cuda'), torch.randn(cb, device='cuda')
+        wp, wn = _ws(L, g)
+        st = L.stream()
+        L.check(L.lib.gan_conv2d_wgrad(gp, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), accumulate, wp, wn, st))
+        # (transposed conv: the SMALL tensor is its input, the big one its output gradient)
+        L.check(L.lib.gan_deconv2d_wgrad(gp, L.ptr(dy), L.ptr(x), L.ptr(dwt), L.ptr(dbt), accumulate, wp, wn, st))
+        torch.cuda.synchronize()
+        outs.append((dw, db, dwt, dbt))
+    for other in outs[1:]:
+        for a, b_ in zip(outs[0], other):
+            assert torch.isfinite(a).all() and torch.equal(a, b_)
+    if not accumulate:
+        torch.testing.assert_close(outs[0][1].double(), dy.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(outs[0][3].double(), x.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-4)
+
+
 def test_split_bf16_arithmetic_is_as_accurate_as_the_fp32_mfma(L):
     """The default contraction arithmetic (fp32 operands split exactly into three bf16 parts, six
     part products on the bf16 matrix pipe, fp32 accumulation) against the float64 oracle, next to
