@@ -32,108 +32,9 @@
 
 #include "common.h"
 
+#include "igemm_common.h"
+
 namespace gan {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { MODE_FPROP = 0, MODE_TPROP = 1, MODE_WGRAD = 2 };
-constexpr int BK = 16;
-constexpr int kMaxClasses = 4;
-
-// n / d for n*d < 2^32 by multiply-high with m = floor(2^32/d) + 1 (d >= 2); d == 1 is a copy.
-struct FastDiv {
-    unsigned d, m;
-};
-
-static FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    f.d = d ? d : 1;
-    f.m = f.d > 1 ? (unsigned)((1ull << 32) / f.d) + 1u : 0u;
-    return f;
-}
-
-// d == 1 has m == 0: the product term vanishes and the (d == 1) term passes n through, branch free
-__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return __umulhi(n, f.m) + n * (unsigned)(f.d == 1u); }
-
-struct ClassInfo {
-    int ph, pw;    // (q + pad) mod stride of this class's output pixels
-    int khc, kwc;  // taps of this class per axis
-    int hq0, wq0;  // first quotient index whose pixel is inside the image
-    int hq, wq;    // quotient extents
-    int M, K;
-    FastDiv d_kwc;
-};
-
-struct IgemmArgs {
-    gan_conv_geom g;
-    const float* a;
-    const float* b;
-    float* out;
-    const float* bias;
-    int M, N, K;  // FPROP / WGRAD problem; TPROP uses cls[].M / cls[].K and N = g.cb
-    int splits, kt_per_split;
-    long slab_elems;
-    int accumulate;
-    int vec_epilogue;  // rows of the output are 16-byte aligned and N % 4 == 0: float4 stores
-    unsigned a_bytes, b_bytes;  // sizes of the two operand tensors (buffer range checks of the split kernel)
-    int ncls;
-    FastDiv d_cb, d_cs, d_kw, d_hsws, d_ws;
-    ClassInfo cls[kMaxClasses];
-    Epilogue epi;  // applied where the final value is stored: here when splits == 1, else by the slab reduction
-    int reflect;   // FPROP / WGRAD: taps that fall outside the big image read its mirror image (tf.pad REFLECT
-                   // by pt / pl in front of a VALID convolution) instead of zeros
-    int row3_spr;  // > 0: filter-row gather of a 3-channel big image (igemm_split.h, ROW3), slices per filter row
-    int grid_mt, grid_nt, grid_z;  // row tiles, column tiles, (parity classes x k splits) of the one-dimensional grid
-    int xcd_order;                 // tile_of_workgroup: 0 / 3 launch order (k range / row tile fastest), 1 / 2 XCD-aware
-    // Workgroups beyond own_blocks carry the last stage of a bias-gradient column sum (its partial sums were left by
-    // a launch ahead of this one).
-    int own_blocks;
-    ColsumFinal tail;
-};
-
-
-// Which tile a workgroup computes.  The grid is one-dimensional.  The hardware hands workgroups to the 8 XCDs
-// round robin in launch order (position L runs on XCD L % 8) and every XCD has an L2 of its own, so tiles that
-// read the same operand bytes should sit on ONE XCD at the same time.  Launch positions are therefore mapped to
-// work indices such that each XCD receives one contiguous range of them, and the work index is decoded with the
-// operand-sharing axis fastest:
-//   order 1 (by row tile)  all parity classes, k splits and column tiles of one row tile are neighbours: they
-//                  gather the same neighbourhood of the image, tap by tap, so the image crosses the fabric once
-//                  and the filter once per XCD (FPROP / TPROP whose image outweighs the filter);
-//   order 2 (by k range)   all row and column tiles of one (class, k split) are neighbours.  WGRAD: a k split is a
-//                  range of images, which every filter tap reads, shifted.  FPROP / TPROP: a k split is a range of
-//                  filter taps, read by every row tile, so a large filter crosses the fabric once.
-// Orders 0 and 3 are plain launch orders (no XCD grouping) with the k range resp. the row tile fastest.
-struct TileId { int mt, nt, z; };
-template <int MODE>
-__device__ __forceinline__ TileId tile_of_workgroup(const IgemmArgs& p) {
-    const unsigned MT = (unsigned)p.grid_mt, NT = (unsigned)p.grid_nt, Z = (unsigned)p.grid_z;
-    const unsigned L = blockIdx.x;
-    unsigned w = L;
-    if (p.xcd_order == 1 || p.xcd_order == 2) {
-        const unsigned T = MT * NT * Z;
-        const unsigned per = (T + 7u) >> 3;                  // work items of a "tall" XCD
-        const unsigned tall = (T & 7u) ? (T & 7u) : 8u;      // XCDs that receive `per` items (the rest per - 1)
-        const unsigned xcd = L & 7u, loc = L >> 3;
-        w = xcd < tall ? xcd * per + loc : tall * per + (xcd - tall) * (per - 1u) + loc;
-    }
-    TileId t;
-    if (MODE == MODE_WGRAD || p.xcd_order >= 2) {     // 3: row tile fastest in plain launch order
-        t.mt = (int)(w % MT);
-        const unsigned r = w / MT;
-        t.nt = (int)(r % NT);
-        t.z = (int)(r / NT);
-    } else {
-        t.z = (int)(w % Z);
-        const unsigned r = w / Z;
-        t.nt = (int)(r % NT);
-        t.mt = (int)(r / NT);
-    }
-    return t;
-}
-
-// index i of an image row / column of n pixels extended by reflection without repeating the edge (|i| < n beyond it)
-__device__ __forceinline__ int reflect_at(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // Raw gather load: masked-off lanes read element 0 of the tensor (always mapped); the zeroing
 // select happens when the registers are written to LDS one slice later, so nothing touches the
@@ -567,8 +468,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         }
     }
 }
-
-#include "igemm_split.h"
 
 // out[i] = (accumulate ? out[i] : 0) + bias[i % c] + sum_s slab[s][i].  The first `own_blocks` workgroups do
 // that; any further ones carry the last stage of the bias-gradient column sum (`tail`).
@@ -1068,8 +967,10 @@ static Plan make_plan(int mode, const IgemmArgs& a, bool a_al, bool b_al) {
     if (N <= 32) pl.cfg = 3;
     else if (N <= 64) pl.cfg = (M >= 8192) ? 1 : 2;
     else pl.cfg = (M >= 2048 && N >= 128) ? 0 : 2;
-    // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4
-    const bool split_ok = a_al && b_al && split_eligible(mode, a) && !exact_f32();
+    // the split kernel's loaders move 16 / 8 bytes at a time: channel counts must be multiples of 4; mirrored taps
+    // are built for its cheap gather arithmetic and for the filter-row gather of 3-channel images only
+    const bool reflect_ok = !a.reflect || row3_slices(mode, g) > 0 || (mode == MODE_FPROP ? g.cb % 16 == 0 : g.ws % 4 == 0);
+    const bool split_ok = a_al && b_al && split_eligible(mode, a) && !exact_f32() && reflect_ok;
     if (split_ok && pl.cfg == 3 && mode == MODE_FPROP) {
         // the same tile on the bf16 pipe (CycleGAN's 64 -> 3 channel 7x7 image head: 163 -> 133 us); the weight
         // gradient of such a layer is faster on the fp32 tile (190 against 245 us) and keeps it
@@ -1209,25 +1110,6 @@ static void launch_vec(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, 1, 1>), grid, dim3(256), 0, s, a);
 }
 
-// The split kernel's cheap gather arithmetic needs 16-channel alignment of the gathered image (FPROP: big
-// side, TPROP: small side) or, for WGRAD, a small-image width that is a multiple of 4.
-template <int MODE, int BM, int BN, int KG = 1, int WM = 2, int WN = 2>
-static void launch_split(const IgemmArgs& a, dim3 grid, hipStream_t s) {
-    const gan_conv_geom& g = a.g;
-    const bool fast = (MODE == MODE_FPROP) ? (g.cb % 16 == 0)
-                    : (MODE == MODE_TPROP) ? (g.cs % 16 == 0) : (g.ws % 4 == 0);
-    if constexpr (MODE != MODE_TPROP) {
-        if (a.row3_spr > 0) {
-            hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, WM, WN, false, KG, true>), grid, dim3(256 * KG), 0, s, a);
-            return;
-        }
-    }
-    if (fast && !knobs().slow_gather)
-        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, WM, WN, true, KG>), grid, dim3(256 * KG), 0, s, a);
-    else
-        hipLaunchKernelGGL((igemm_split_kernel<MODE, BM, BN, WM, WN, false, KG>), grid, dim3(256 * KG), 0, s, a);
-}
-
 template <int MODE>
 static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_t s) {
     switch (pl.cfg) {
@@ -1235,14 +1117,16 @@ static void launch_cfg(const IgemmArgs& a, const Plan& pl, dim3 grid, hipStream_
         case 1: launch_vec<MODE, 128, 64, 2, 2>(a, pl, grid, s); break;
         case 2: launch_vec<MODE, 64, 64, 2, 2>(a, pl, grid, s); break;
         case 3: launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break;
-        case 4: launch_split<MODE, 128, 128>(a, grid, s); break;
-        case 5: launch_split<MODE, 128, 64>(a, grid, s); break;
-        case 6: launch_split<MODE, 64, 64>(a, grid, s); break;
-        case 7: launch_split<MODE, 128, 128, 2>(a, grid, s); break;
-        case 8: launch_split<MODE, 128, 64, 2>(a, grid, s); break;
         default:
-            if constexpr (MODE != MODE_TPROP) launch_split<MODE, 128, 32, 1, 4, 1>(a, grid, s);   // (make_plan maps TPROP to 3)
-            else launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s);
+            if (pl.cfg == kThinSplitCfg && MODE == MODE_TPROP) { launch_vec<MODE, 128, 32, 4, 1>(a, pl, grid, s); break; }   // (make_plan maps TPROP to 3)
+            {
+                typedef void (*Launcher)(const IgemmArgs&, int, bool, dim3, hipStream_t);
+                static const Launcher table[3][3] = {{launch_split_m0_p0, launch_split_m0_p1, launch_split_m0_p2},
+                                                     {launch_split_m1_p0, launch_split_m1_p1, launch_split_m1_p2},
+                                                     {launch_split_m2_p0, launch_split_m2_p1, launch_split_m2_p2}};
+                const int part = (pl.cfg == 4 || pl.cfg == 7) ? 0 : ((pl.cfg == 5 || pl.cfg == 8) ? 1 : 2);
+                table[MODE][part](a, pl.cfg, knobs().slow_gather != 0, grid, s);
+            }
             break;
     }
 }

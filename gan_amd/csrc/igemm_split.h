@@ -1,5 +1,5 @@
 // fp32 contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), gfx950.
-// Included by igemm.hip inside namespace gan, after IgemmArgs / ClassInfo / fdiv.
+// Included by igemm_split_tu.hip inside namespace gan, after igemm_common.h (IgemmArgs / ClassInfo / fdiv).
 //
 // The fp32 MFMA runs at the vector rate (64 FLOP/clk/SIMD); the bf16 MFMA is 16 times faster.
 // An fp32 value x is written EXACTLY as the sum of three bf16 values h + m + l (each holds the next
@@ -68,8 +68,13 @@ __device__ __forceinline__ int unpermute(int pos) {
 // floats in memory, padded to p.row3_spr slices of 16 (the pad multiplies zeros).  Element e of the run is column
 // x0 + e / 3, channel e % 3, loaded as one dword with its own range check: neither a per-element tap decode nor
 // vector alignment is needed.  FPROP: the virtual K is kh * spr * 16; WGRAD: the virtual M.
-template <int MODE, int BM, int BN, int WM, int WN, bool FAST, int KG = 1, bool ROW3 = false>
+//
+// REFLECT (FPROP / WGRAD): taps outside the big image read its mirror image (the `reflect` flag of the fp32 kernel as
+// a compile-time switch: a run-time branch inside the slice loop would split it into basic blocks, and the pinned
+// MFMA / vector interleave and the counted waits on the loads in flight only hold inside one block).
+template <int MODE, int BM, int BN, int WM, int WN, bool FAST, int KG = 1, bool ROW3 = false, bool REFLECT = false>
 __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p) {
+    static_assert(!REFLECT || MODE != MODE_TPROP, "mirrored taps: forward and weight gradient only");
     static_assert(!ROW3 || (MODE != MODE_TPROP && !FAST), "the filter-row gather serves FPROP and WGRAD, general arithmetic");
     static_assert(WM * WN == 4, "four waves per block");
     static_assert(BM % 64 == 0 && BN % 32 == 0, "tile sides are multiples of 64 rows and 32 columns");
@@ -212,7 +217,10 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         for (int j = 0; j < 4; ++j) b_cj[j] = (unsigned)((b_kq * 4 + j) * N + n0 + 2 * b_rc) * 4u;
     }
     const bool b_pair_valid = b_on & (n0 + 2 * b_rc < N);
-    // an odd N: the last column has no partner (what follows it in memory is the next k row)
+    // an odd N: the last column has no partner.  The pair load then fetches the first value of the next k row (or, at
+    // the very end, what the buffer range check makes of it) beside it; that value is replaced by zero when the slice
+    // is written to LDS -- a select there, not a branch around the load here, which would cut the slice loop into
+    // basic blocks and force a wait on every load behind it.
     const bool b_single = !B_TRANS && (n0 + 2 * b_rc + 1 == N);
 
     typedef float AReg[A_PASS][A_W];
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     auto r3_off = [&](int rowbase, int x0, int e, bool ok) -> unsigned {
         const int tc = (e * 11) >> 5;      // e / 3 for e < 32
         int col = x0 + tc;
-        if (p.reflect) col = reflect_at(col, g.wb);
+        if constexpr (REFLECT) col = reflect_at(col, g.wb);
         ok = ok & (e < r3_len) & ((unsigned)col < (unsigned)g.wb);
         return ok ? (unsigned)((rowbase + col) * 3 + (e - 3 * tc)) * 4u : kOutOfRange;
     };
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
                 int iy = a_y0[ps] + ta;
-                if (p.reflect) iy = reflect_at(iy, SH);
+                if constexpr (REFLECT) iy = reflect_at(iy, SH);
                 const bool rowok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH);
                 const int rowbase = a_base[ps] + iy * SW;
 #pragma unroll
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 const int oy = fdiv(rem, p.d_ws);
                 const int ox = rem - oy * g.ws;
                 int iy = oy * g.sh + w_ta - g.pt;
-                if (p.reflect) iy = reflect_at(iy, g.hb);
+                if constexpr (REFLECT) iy = reflect_at(iy, g.hb);
                 const bool rowok = kv & ((unsigned)iy < (unsigned)g.hb);
                 const int rowbase = (img * g.hb + iy) * g.wb, x0 = ox * g.sw - g.pl;
                 ld1(rsrc_a, r3_off(rowbase, x0, w_e, rowok), a_reg[j][0]);
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             const int sgn = (MODE == MODE_TPROP) ? -1 : 1;
             const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((sgn * (ta * SW + tb) * SC + cc0) * 4);
             const bool kv = (int)k0 + t_kq * 4 < kend;
-            if (MODE == MODE_FPROP && p.reflect) {
+            if constexpr (MODE == MODE_FPROP && REFLECT) {
                 // mirrored taps: the offset is no longer base + per-slice constant
                 const unsigned uc = (unsigned)__builtin_amdgcn_readfirstlane(cc0 * 4) + t_kq * 16;
 #pragma unroll
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 for (int ps = 0; ps < A_PASS; ++ps) {
                     int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
                     int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
-                    if (MODE == MODE_FPROP && p.reflect) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
+                    if constexpr (MODE == MODE_FPROP && REFLECT) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
                     const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
                     const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
                     if (halves == 1) {
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             const int oy = fdiv(rem, p.d_ws);
             const int ox = rem - oy * g.ws;
             const int iy = oy * g.sh + a_kh - g.pt, ix0 = ox * g.sw + a_kw - g.pl;
-            if (p.reflect) {
+            if constexpr (REFLECT) {
                 const unsigned rowb = (unsigned)((img * g.hb + reflect_at(iy, g.hb)) * g.wb);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 const int oy = fdiv(rem, p.d_ws);
                 const int ox = rem - oy * g.ws;
                 int iy = oy * g.sh + a_kh - g.pt, ix = ox * g.sw + a_kw - g.pl;
-                if (p.reflect) { iy = reflect_at(iy, g.hb); ix = reflect_at(ix, g.wb); }
+                if constexpr (REFLECT) { iy = reflect_at(iy, g.hb); ix = reflect_at(ix, g.wb); }
                 const bool ok = kv & ((unsigned)iy < (unsigned)g.hb) & ((unsigned)ix < (unsigned)g.wb);
                 const unsigned off = (unsigned)(((img * g.hb + iy) * g.wb + ix) * g.cb + a_c) * 4u;
                 ld2(rsrc_a, ok ? off : kOutOfRange, a_reg[j]);
@@ -424,8 +432,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned off = (b_pair_valid & kv & (eb + b_kq * 4 + j < r3_len)) ? b_cj[j] + u : kOutOfRange;
-                if (b_single) { ld1(rsrc_b, off, b_reg[j][0]); b_reg[j][1] = 0.f; }
-                else ld2(rsrc_b, off, b_reg[j]);
+                ld2(rsrc_b, off, b_reg[j]);
             }
         } else {
             // row-major [K][N]: a constant of the thread per k row plus the slice's scalar offset
@@ -434,8 +441,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned off = (b_pair_valid & (kb + j < kend)) ? b_cj[j] + u : kOutOfRange;
-                if (b_single) { ld1(rsrc_b, off, b_reg[j][0]); b_reg[j][1] = 0.f; }
-                else ld2(rsrc_b, off, b_reg[j]);
+                ld2(rsrc_b, off, b_reg[j]);
             }
         }
     };
@@ -474,9 +480,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 put(Bs, PB, GB, t_kq, t_r + ps * 64, b_reg[ps][0], b_reg[ps][1], b_reg[ps][2], b_reg[ps][3]);
         } else {
             if (b_on) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    put(Bs, PB, GB, b_kq, e * (BN / 2) + b_rc, b_reg[0][e], b_reg[1][e], b_reg[2][e], b_reg[3][e]);
+                put(Bs, PB, GB, b_kq, b_rc, b_reg[0][0], b_reg[1][0], b_reg[2][0], b_reg[3][0]);
+                put(Bs, PB, GB, b_kq, BN / 2 + b_rc, b_single ? 0.f : b_reg[0][1], b_single ? 0.f : b_reg[1][1],
+                    b_single ? 0.f : b_reg[2][1], b_single ? 0.f : b_reg[3][1]);
             }
         }
     };
