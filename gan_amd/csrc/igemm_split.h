@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         int col = x0 + tc;
         if constexpr (REFLECT) col = reflect_at(col, g.wb);
         ok = ok & (e < r3_len) & ((unsigned)col < (unsigned)g.wb);
-        return ok ? (unsigned)((rowbase + col) * 3 + (e - 3 * tc)) * 4u : kOutOfRange;
+        // (the offset is worked out unconditionally: with the arithmetic inside the conditional expression the compiler
+        // keeps a branch around it, and a branch splits the slice loop's basic block)
+        const unsigned off = (unsigned)((rowbase + col) * 3 + (e - 3 * tc)) * 4u;
+        return ok ? off : kOutOfRange;
     };
 
     auto load_a = [&](int kt, AReg& a_reg) {
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 for (int ps = 0; ps < A_PASS; ++ps) {
                     const int iy = reflect_at(a_y0[ps] + ta, SH), ix = reflect_at(a_x0[ps] + tb, SW);
                     const bool ok = kv & (a_base[ps] >= 0);
-                    ld4(rsrc_a, ok ? (unsigned)((a_base[ps] + iy * SW + ix) * SC) * 4u + uc : kOutOfRange, a_reg[ps]);
+                    const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC) * 4u + uc;
+                    ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
                 }
             } else {
 #pragma unroll
@@ -311,11 +315,32 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 }
             }
         } else if constexpr (A_TRANS) {
-            // (pairs: a gathered channel count that is even but no multiple of 4 -- four consecutive k may straddle two
-            // taps, two cannot -- decodes each half of the thread's quad on its own and loads it 8 bytes at a time)
-            const int halves = (MODE == MODE_TPROP && (SC & 3)) ? 2 : 1;
-            for (int hf = 0; hf < halves; ++hf) {
-                const int k = kt * BK + t_kq * 4 + 2 * hf;
+            if constexpr (MODE == MODE_TPROP) {
+                // pairs: the gathered channel count may be even but no multiple of 4 -- four consecutive k can then
+                // straddle two taps, two cannot -- so each half of the thread's quad is decoded on its own and loaded 8
+                // bytes at a time (straight-line code: a trip count or a branch on `cs % 4` would split the slice loop)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int k = kt * BK + t_kq * 4 + 2 * hf;
+                    const bool kv = k < kend;
+                    const unsigned uk = kv ? (unsigned)k : 0u;
+                    const int tapc = fdiv(uk, dSC);
+                    const int cc = uk - tapc * SC;
+                    const int ta = fdiv(tapc, dTW);
+                    const int tb = tapc - ta * (int)dTW.d;
+#pragma unroll
+                    for (int ps = 0; ps < A_PASS; ++ps) {
+                        const int iy = a_y0[ps] - ta, ix = a_x0[ps] - tb;
+                        const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
+                        const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
+                        float two[2];
+                        ld2(rsrc_a, ok ? off : kOutOfRange, two);
+                        a_reg[ps][2 * hf] = two[0];
+                        a_reg[ps][2 * hf + 1] = two[1];
+                    }
+                }
+            } else {
+                const int k = kt * BK + t_kq * 4;
                 const bool kv = k < kend;
                 const unsigned uk = kv ? (unsigned)k : 0u;
                 const int tapc = fdiv(uk, dSC);
@@ -324,19 +349,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 const int tb = tapc - ta * (int)dTW.d;
 #pragma unroll
                 for (int ps = 0; ps < A_PASS; ++ps) {
-                    int iy = (MODE == MODE_TPROP) ? a_y0[ps] - ta : a_y0[ps] + ta;
-                    int ix = (MODE == MODE_TPROP) ? a_x0[ps] - tb : a_x0[ps] + tb;
-                    if constexpr (MODE == MODE_FPROP && REFLECT) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
+                    int iy = a_y0[ps] + ta, ix = a_x0[ps] + tb;
+                    if constexpr (REFLECT) { iy = reflect_at(iy, SH); ix = reflect_at(ix, SW); }
                     const bool ok = kv & (a_base[ps] >= 0) & ((unsigned)iy < (unsigned)SH) & ((unsigned)ix < (unsigned)SW);
                     const unsigned off = (unsigned)((a_base[ps] + iy * SW + ix) * SC + cc) * 4u;
-                    if (halves == 1) {
-                        ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
-                    } else {
-                        float two[2];
-                        ld2(rsrc_a, ok ? off : kOutOfRange, two);
-                        a_reg[ps][2 * hf] = two[0];
-                        a_reg[ps][2 * hf + 1] = two[1];
-                    }
+                    ld4(rsrc_a, ok ? off : kOutOfRange, a_reg[ps]);
                 }
             }
         } else if constexpr (FAST) {
@@ -354,7 +371,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ix = reflect_at(ix0 + j * g.sw, g.wb);
-                    ld2(rsrc_a, kv ? (unsigned)((rowb + ix) * g.cb + a_c) * 4u : kOutOfRange, a_reg[j]);
+                    const unsigned off = (unsigned)((rowb + ix) * g.cb + a_c) * 4u;
+                    ld2(rsrc_a, kv ? off : kOutOfRange, a_reg[j]);
                 }
             } else {
                 const bool rowok = kv & ((unsigned)iy < (unsigned)g.hb);
@@ -398,8 +416,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) ld4(rsrc_b, (kv & b_nvalid[ps]) ? b_rb[ps] + u : kOutOfRange, b_reg[ps]);
         } else if constexpr (B_TRANS) {
-            const int halves = (g.cs & 3) ? 2 : 1;   // (pairs, as for A)
-            for (int hf = 0; hf < halves; ++hf) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {     // (pairs, as for A)
                 const int k = kt * BK + t_kq * 4 + 2 * hf;
                 const bool kv = k < kend;
                 const unsigned uk = kv ? (unsigned)k : 0u;
@@ -413,14 +431,10 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                     const int n = n0 + t_r + ps * 64;
                     const bool ok = kv & (n < N);
                     const unsigned off = (unsigned)((wtap * g.cb + n) * g.cs + cc) * 4u;
-                    if (halves == 1) {
-                        ld4(rsrc_b, ok ? off : kOutOfRange, b_reg[ps]);
-                    } else {
-                        float two[2];
-                        ld2(rsrc_b, ok ? off : kOutOfRange, two);
-                        b_reg[ps][2 * hf] = two[0];
-                        b_reg[ps][2 * hf + 1] = two[1];
-                    }
+                    float two[2];
+                    ld2(rsrc_b, ok ? off : kOutOfRange, two);
+                    b_reg[ps][2 * hf] = two[0];
+                    b_reg[ps][2 * hf + 1] = two[1];
                 }
             }
         } else if constexpr (ROW3 && MODE == MODE_FPROP) {
