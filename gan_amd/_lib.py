@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgan_hip.so")
+# GAN_HIP_LIB names another build of the same library (the probe build with in-kernel clock stamps, tools/phase_probe.py)
+LIB_PATH = os.environ.get("GAN_HIP_LIB") or os.path.join(_HERE, "lib", "libgan_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

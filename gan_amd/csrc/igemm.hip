@@ -1273,6 +1273,11 @@ size_t igemm_ws_bytes(int mode, IgemmArgs a) {
     return al > un ? al : un;
 }
 
+#ifdef GAN_PHASE_STAMPS
+static long long* g_debug_stamps = nullptr;
+extern "C" void gan_debug_set_stamps(long long* p) { g_debug_stamps = p; }
+#endif
+
 IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const float* b, float* out,
                     const float* bias, int accumulate) {
     IgemmArgs r;
@@ -1284,6 +1289,9 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.reflect = 0;
     r.row3_spr = 0;
     r.own_blocks = 0x7fffffff;
+#ifdef GAN_PHASE_STAMPS
+    r.stamps = g_debug_stamps;
+#endif
     r.tail = ColsumFinal{nullptr, nullptr, 0, 0, 0, 0};
     r.d_cb = make_fastdiv((unsigned)g.cb);
     r.d_cs = make_fastdiv((unsigned)g.cs);

@@ -62,6 +62,9 @@ struct IgemmArgs {
     // a launch ahead of this one).
     int own_blocks;
     ColsumFinal tail;
+#ifdef GAN_PHASE_STAMPS
+    long long* stamps;  // probe builds: [workgroup][8] clock stamps (igemm_split.h)
+#endif
 };
 
 

@@ -25,6 +25,16 @@
 //     addresses; the epilogue undoes that row permutation.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Probe builds only (make STAMPS=1 -> libgan_hip_stamps.so, tools/phase_probe.py): thread 0 of every workgroup
+// leaves the constant-rate 100 MHz clock at six points of the kernel in p.stamps[workgroup][0..5], and the shader
+// clock counter around the slice loop in [6..7] (their ratio is the clock the chip holds inside the loop).
+#ifdef GAN_PHASE_STAMPS
+#define GAN_STAMP(i) do { if (threadIdx.x == 0 && p.stamps) { p.stamps[(long)blockIdx.x * 8 + (i)] = (long long)wall_clock64(); \
+        if ((i) == 2 || (i) == 3) p.stamps[(long)blockIdx.x * 8 + 4 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define GAN_STAMP(i) do { } while (0)
+#endif
+
 // The gathers go through buffer descriptors: a masked-off lane (padding tap, row beyond the problem,
 // tail of K) presents an offset beyond the buffer and the hardware range check returns zeros, so
 // neither the address nor the loaded values need a select per element.
@@ -34,6 +44,12 @@ constexpr unsigned kOutOfRange = 0xfffffff0u;
 
 // x0, x1 -> packed bf16 pairs (x0 in the low half) of the three parts
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef GAN_ABLATE_SPLIT   // probe builds: one instruction per part instead of the exact split (wrong results)
+    h = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    m = h ^ 0x00010001u;
+    l = h ^ 0x00020002u;
+    return;
+#endif
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);   // exact: the low 16 significand bits
     const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
@@ -95,6 +111,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         if (threadIdx.x < 256) colsum_final_block(p.tail, (int)blockIdx.x - p.own_blocks);
         return;
     }
+    GAN_STAMP(0);
     const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
     unsigned char* const smem_raw = smem_all + kgrp * (2 * STAGE);
     const int tid = threadIdx.x & 255;
@@ -230,12 +247,20 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
     auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off, float (&dst)[4]) {
+#ifdef GAN_ABLATE_GLOAD   // probe builds: no memory operation, the offset stays live (wrong results)
+        const u32x4 v = {byte_off, byte_off + 1u, byte_off + 2u, byte_off + 3u};
+#else
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+#endif
         dst[0] = __uint_as_float(v[0]); dst[1] = __uint_as_float(v[1]);
         dst[2] = __uint_as_float(v[2]); dst[3] = __uint_as_float(v[3]);
     };
     auto ld2 = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off, float (&dst)[2]) {
+#ifdef GAN_ABLATE_GLOAD
+        const u32x2 v = {byte_off, byte_off + 1u};
+#else
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+#endif
         dst[0] = __uint_as_float(v[0]); dst[1] = __uint_as_float(v[1]);
     };
 
@@ -467,9 +492,13 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         split3(x0, x1, h01, m01, l01);
         split3(x2, x3, h23, m23, l23);
         unsigned char* q = img + (kq >> 1) * group_bytes + pos * 16 + (kq & 1) * 8;
+#ifdef GAN_ABLATE_LDSW    // probe builds: the parts stay live, nothing is written (wrong results)
+        asm volatile("" :: "v"(h01), "v"(h23), "v"(m01), "v"(m23), "v"(l01), "v"(l23), "v"(q));
+#else
         *reinterpret_cast<uint2*>(q) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(q + part_bytes) = make_uint2(m01, m23);
         *reinterpret_cast<uint2*>(q + 2 * part_bytes) = make_uint2(l01, l23);
+#endif
     };
 
     auto store_a = [&](int buf, const AReg& a_reg) {
@@ -522,10 +551,17 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+#ifdef GAN_ABLATE_LDSR    // probe builds: fragments made up in registers (wrong results)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { unsigned u = (unsigned)(size_t)(As + s * PA + frag_a + i * 32 * 16); asm volatile("" : "+v"(u)); af[s][i] = __builtin_bit_cast(bf16x8, u32x4{u, u, u, u}); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { unsigned u = (unsigned)(size_t)(Bs + s * PB + frag_b + j * 32 * 16); asm volatile("" : "+v"(u)); bf[s][j] = __builtin_bit_cast(bf16x8, u32x4{u, u, u, u}); }
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(As + s * PA + frag_a + i * 32 * 16);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(Bs + s * PB + frag_b + j * 32 * 16);
+#endif
         }
         store_a(buf ^ 1, ra);
         store_b(buf ^ 1, rb);
@@ -537,12 +573,16 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 c = acc[i][j];
+#ifdef GAN_ABLATE_MFMA    // probe builds: the fragments stay live, nothing is multiplied (wrong results)
+                asm volatile("" :: "v"(af[0][i]), "v"(af[1][i]), "v"(af[2][i]), "v"(bf[0][j]), "v"(bf[1][j]), "v"(bf[2][j]));
+#else
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
+#endif
                 acc[i][j] = c;
             }
         // Interleave: the matrix pipe needs 32 cycles per MFMA of which the issue port is busy for 8, so
@@ -558,6 +598,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    GAN_STAMP(1);
     if (per_group > 0) {
         // Software pipeline with two register sets and two LDS buffers, one barrier per slice
         // (slices past the end load zeros and are never multiplied).
@@ -572,6 +613,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
         load_a(kt0 + 2, a0);
         load_b(kt0 + 2, b0);
         __syncthreads();
+        GAN_STAMP(2);
         // two slices per trip keep the register sets and LDS buffers compile-time; an odd slice count
         // multiplies one slice of zeros at the end
         for (int kt = kt0; kt < kt0 + per_group; kt += 2) {
@@ -579,6 +621,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             slice(1, a0, b0, kt + 4);
         }
     }
+    GAN_STAMP(3);
     if constexpr (KG > 1) {
         // the second group's accumulators -> LDS (register-major: conflict free), first group adds them and goes on
         // alone; a wave that has ended no longer counts at the barriers of the epilogue
@@ -601,6 +644,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 256 + tid];
     }
 
+    GAN_STAMP(4);
     // ---------------------------------------------------------------- epilogue (as igemm_kernel, plus the
     // row / column permutation of operands filled by the row-pair loader)
     // (staging reuses the buffers, the hand-over area included: the barrier behind the row table below comes after
@@ -685,6 +729,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
             }
             if (r0 + R < BM) __syncthreads();
         }
+        GAN_STAMP(5);
         return;
     }
 
