@@ -102,7 +102,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     constexpr int PA = 2 * GA, PB = 2 * GB;                // one part of a 16-deep slice
     constexpr int STAGE = 3 * (PA + PB);
     // vector instructions of one slice (split, address arithmetic) per MFMA of that slice
+#ifdef GAN_VALU_PER_MFMA   // (experiments: the interleave density of the 128 x 128 tiles)
+    constexpr int kValuPerMfma = (TM * TN >= 4) ? GAN_VALU_PER_MFMA : (TM * TN == 2 ? (FAST ? 8 : 11) : (FAST ? 14 : 20));
+#else
     constexpr int kValuPerMfma = (TM * TN >= 4) ? (FAST ? 5 : 7) : (TM * TN == 2 ? (FAST ? 8 : 11) : (FAST ? 14 : 20));
+#endif
     static_assert(KG == 1 || KG == 2, "one or two k groups");
     static_assert(KG == 1 || TM * TN * 16 * 256 * 4 <= KG * 2 * STAGE, "the accumulator hand-over must fit the staging buffers");
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[KG * 2 * STAGE];
