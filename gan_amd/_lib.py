@@ -39,6 +39,12 @@ class BnMovingJob(ctypes.Structure):
                 ("save_rstd", ctypes.c_void_p), ("rows", ctypes.c_int), ("c", ctypes.c_int)]
 
 
+class BnSaved(ctypes.Structure):
+    """gan_bn_saved of include/gan_hip.h."""
+    _fields_ = [("x", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("save_mean", ctypes.c_void_p),
+                ("save_rstd", ctypes.c_void_p), ("groups", ctypes.c_int), ("act", ctypes.c_int), ("act_param", ctypes.c_float)]
+
+
 GeomP = ctypes.POINTER(ConvGeom)
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
@@ -72,6 +78,12 @@ SIGNATURES = {
     "gan_bn_moving_update_multi": (I, [ctypes.POINTER(BnMovingJob), I, F, F, I, P]),
     "gan_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, F, I, F, P]),
     "gan_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, Z, P]),
+    "gan_bn_tile_blocks": (I, [I, I, I, I]),
+    "gan_conv_fwd_bn_stats": (I, [I, GeomP, P, P, P, P, I, P, P, Z, P]),
+    "gan_bn_fwd_train_from_stats": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, I, F, P, P]),
+    "gan_conv_dgrad_bn_sums": (I, [I, GeomP, P, P, P, ctypes.POINTER(BnSaved), P, P, Z, P]),
+    "gan_bn_bwd_tiled": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, I, P, P]),
+    "gan_conv_wgrad_colsum": (I, [I, GeomP, P, P, P, P, I, P, I, P, Z, P]),
     "gan_act_fwd": (I, [P, P, L, I, F, F, F, P]),
     "gan_act_bwd": (I, [P, P, P, L, I, F, F, F, P]),
     "gan_add_fwd": (I, [P, P, P, L, P]),
@@ -100,6 +112,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
+OP_CONV2D, OP_DECONV2D, OP_CONV2D_REFLECT = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU,
              'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}

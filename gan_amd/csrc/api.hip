@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "bn_tile.h"
 
 namespace gan {
 
@@ -72,6 +73,7 @@ Knobs& knobs() {
         r.rgb_gather = env_int("GAN_HIP_RGB_GATHER", 1);
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
         r.no_carry = getenv("GAN_HIP_NO_CARRY") != nullptr;
+        r.no_bn_ride = env_int("GAN_HIP_NO_BN_RIDE", 0);
         return r;
     }();
     return k;
@@ -321,6 +323,76 @@ extern "C" int gan_deconv2d_wgrad(const gan_conv_geom* g, const float* x, const 
                            as_stream(stream), "gan_deconv2d_wgrad");
 }
 
+// ---------------------------------------------------------------------------- batch norm riding on a contraction
+// A conv / deconv in front of a training-mode batch norm leaves the norm's block statistics behind; an input gradient
+// that feeds a batch norm's backward leaves that backward's block sums behind.  In both cases the reduction runs in
+// the launch that sums the contraction's split-K slabs (one launch instead of two, and the finished tensor is not
+// read back for it); without a slab reduction it is a launch of its own behind the contraction, so the caller finds
+// the partial results either way.
+static int bn_ride_shape(const char* what, int op, const gan_conv_geom& g, bool output_big, int groups, bool backward, TileBn* ts) {
+    GAN_CHECK_ARG(op >= GAN_OP_CONV2D && op <= GAN_OP_CONV2D_REFLECT, "%s: unknown op %d", what, op);
+    const long rows_all = output_big ? (long)g.n * g.hb * g.wb : (long)g.n * g.hs * g.ws;
+    const int c = output_big ? g.cb : g.cs;
+    GAN_CHECK_ARG(groups > 0 && rows_all % groups == 0, "%s: %ld output rows do not split into %d groups", what, rows_all, groups);
+    GAN_CHECK_ARG(rows_all / groups < (1L << 31) && bn_ride_plan(groups, (int)(rows_all / groups), c, backward, ts),
+                  "%s: no block decomposition exists for %d x %ld x %d (gan_bn_tile_blocks reports 0)", what, groups,
+                  rows_all / groups, c);
+    return 0;
+}
+
+extern "C" int gan_conv_fwd_bn_stats(int op, const gan_conv_geom* g, const float* x, const float* w, const float* bias,
+                                     float* y, int groups, float* bn_partial, void* ws, size_t ws_bytes,
+                                     gan_stream_t stream) {
+    const char* what = "gan_conv_fwd_bn_stats";
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(bn_partial != nullptr, "%s: NULL tensor", what);
+    TileBn ts;
+    if (int rc = bn_ride_shape(what, op, *g, op == GAN_OP_DECONV2D, groups, false, &ts)) return rc;
+    pending_bn_ride() = BnRide{1, reinterpret_cast<float2*>(bn_partial), ts, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
+    const int rc = op == GAN_OP_CONV2D ? gan_conv2d_fwd(g, x, w, bias, y, ws, ws_bytes, stream)
+                 : op == GAN_OP_DECONV2D ? gan_deconv2d_fwd(g, x, w, bias, y, ws, ws_bytes, stream)
+                                         : gan_conv2d_fwd_reflect(g, x, w, bias, y, ws, ws_bytes, stream);
+    pending_bn_ride().kind = 0;   // (a call that failed its argument checks never took it)
+    return rc;
+}
+
+extern "C" int gan_conv_dgrad_bn_sums(int op, const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                                      const gan_bn_saved* bn, float* bn_partial, void* ws, size_t ws_bytes,
+                                      gan_stream_t stream) {
+    const char* what = "gan_conv_dgrad_bn_sums";
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(bn != nullptr && bn_partial != nullptr && bn->x && bn->gamma && bn->beta && bn->save_mean && bn->save_rstd,
+                  "%s: NULL tensor", what);
+    GAN_CHECK_ARG(bn->act >= GAN_ACT_NONE && bn->act <= GAN_ACT_SIGMOID, "%s: unknown activation %d", what, bn->act);
+    TileBn ts;
+    if (int rc = bn_ride_shape(what, op, *g, op != GAN_OP_DECONV2D, bn->groups, true, &ts)) return rc;
+    pending_bn_ride() = BnRide{2, reinterpret_cast<float2*>(bn_partial), ts, bn->x, bn->gamma, bn->beta, bn->save_mean,
+                               bn->save_rstd, bn->act, bn->act_param};
+    const int rc = op == GAN_OP_CONV2D ? gan_conv2d_dgrad(g, dy, w, dx, ws, ws_bytes, stream)
+                 : op == GAN_OP_DECONV2D ? gan_deconv2d_dgrad(g, dy, w, dx, ws, ws_bytes, stream)
+                                         : gan_conv2d_dgrad_reflect(g, dy, w, dx, ws, ws_bytes, stream);
+    pending_bn_ride().kind = 0;
+    return rc;
+}
+
+extern "C" int gan_conv_wgrad_colsum(int op, const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
+                                     int accumulate, const float* colsum_partial, int colsum_blocks, void* ws,
+                                     size_t ws_bytes, gan_stream_t stream) {
+    const char* what = "gan_conv_wgrad_colsum";
+    if (int rc = conv_geom_check(g)) return rc;
+    GAN_CHECK_ARG(op >= GAN_OP_CONV2D && op <= GAN_OP_CONV2D_REFLECT, "%s: unknown op %d", what, op);
+    GAN_CHECK_ARG(x && dy && dw && db && colsum_partial && colsum_blocks > 0, "%s: NULL tensor", what);
+    hipStream_t st = as_stream(stream);
+    const int c = op == GAN_OP_DECONV2D ? g->cb : g->cs;
+    const ColsumFinal job = ColsumFinal{colsum_partial, db, c, colsum_blocks, accumulate, (c + 3) / 4};
+    int done = 0, rc;
+    if (op == GAN_OP_CONV2D) rc = run_igemm_geom(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, ws_bytes, st, what, &job, &done);
+    else if (op == GAN_OP_DECONV2D) rc = run_igemm_geom(MODE_WGRAD, *g, dy, x, dw, nullptr, accumulate, g->cs, ws, ws_bytes, st, what, &job, &done);
+    else rc = run_igemm_geom_reflect(MODE_WGRAD, *g, x, dy, dw, nullptr, accumulate, g->cs, ws, ws_bytes, st, what, &job, &done);
+    if (rc) return rc;
+    return done ? 0 : colsum_final(job, st, what);
+}
+
 // ---------------------------------------------------------------------------- thin linear
 // ops.linear onto a handful of outputs (the discriminator's final logit: 8192 -> 1) is three
 // matrix-vector products; the 32-wide MFMA tile would be almost all padding.  They are plain
@@ -530,6 +602,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "tile_order")) k.tile_order = value;
     else if (!strcmp(name, "rgb_gather")) k.rgb_gather = value;
     else if (!strcmp(name, "no_carry")) k.no_carry = value != 0;
+    else if (!strcmp(name, "no_bn_ride")) k.no_bn_ride = value;
     else return fail("gan_knob_set: unknown knob '%s'", name);
     return 0;
 }

@@ -39,6 +39,8 @@ struct Knobs {
     int rgb_gather;       // GAN_HIP_RGB_GATHER: filter-row gather for 3-channel images: 1 FPROP and WGRAD, 2 WGRAD only, 0 off
     int tile_order;       // GAN_HIP_TILE_ORDER: 0 chosen per launch, 1 launch order, 2 by row tile, 3 by k range
     int exact_f32;      // GAN_HIP_EXACT_F32: default of gan_set_exact_f32
+    int no_bn_ride;     // GAN_HIP_NO_BN_RIDE: 1 gan_bn_tile_blocks reports 0 (callers keep the separate batch-norm launches); 2 the
+                        // reductions asked for run as launches of their own behind the contraction instead of riding
     int no_carry;       // GAN_HIP_NO_CARRY: the last stage of a bias-gradient column sum never rides on a contraction launch
 };
 Knobs& knobs();
@@ -114,7 +116,7 @@ struct Epilogue {
     const float* gate;
 };
 
-__device__ __forceinline__ bool epi_active(const Epilogue& e) {
+__host__ __device__ __forceinline__ bool epi_active(const Epilogue& e) {
     return e.gate != nullptr || e.act != GAN_ACT_NONE || e.scale != 1.f || e.shift != 0.f;
 }
 

@@ -33,6 +33,7 @@
 #include "common.h"
 
 #include "igemm_common.h"
+#include "bn_tile.h"
 
 namespace gan {
 
@@ -1177,10 +1178,27 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
               const ColsumFinal* tail = nullptr, int* tail_done = nullptr, const FoldReflect* fold = nullptr) {
     ColsumFinal job = ColsumFinal{nullptr, nullptr, 0, 0, 0, 0};
     if (tail != nullptr && tail_done != nullptr && tail->blocks > 0) job = *tail;
+    // a batch-norm reduction over the output, asked for by the entry point that called (taken: it never outlives the call)
+    const BnRide ride = pending_bn_ride();
+    pending_bn_ride().kind = 0;
+    if (ride.kind != 0) {
+        const long out_elems = mode == MODE_TPROP ? (fold ? (long)fold->n * fold->h * fold->w * fold->c : (long)a.g.n * a.g.hb * a.g.wb * a.g.cb)
+                                                  : (long)a.g.n * a.g.hs * a.g.ws * a.g.cs;
+        GAN_CHECK_ARG(mode != MODE_WGRAD && job.blocks == 0 && !a.accumulate && !epi_active(a.epi) && ride.s.c == out_c &&
+                      (long)ride.s.groups * ride.s.rows * ride.s.c == out_elems,
+                      "%s: the batch-norm reduction does not fit this contraction's output", what);
+    }
+    // the reduction over the finished output, as a launch of its own (no slab reduction launch to ride on)
+    auto ride_alone = [&](float* out) -> int {
+        return launch_bn_ride(ride, RowSource{nullptr, out, nullptr, 0, 0}, s, what);
+    };
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
     if (mode == MODE_TPROP && thin_tprop_ok(a)) {
-        if (fold == nullptr) return run_thin_tprop(a, s, what);
+        if (fold == nullptr) {
+            if (int rc = run_thin_tprop(a, s, what)) return rc;
+            return ride.kind ? ride_alone(a.out) : 0;
+        }
         const long elems = (long)a.g.n * a.g.hb * a.g.wb * a.g.cb;
         GAN_CHECK_ARG(ws != nullptr && ws_bytes >= (size_t)elems * sizeof(float), "%s: workspace of %zu bytes needed, %zu given",
                       what, (size_t)elems * sizeof(float), ws_bytes);
@@ -1188,7 +1206,8 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         a.out = static_cast<float*>(ws);
         if (int rc = run_thin_tprop(a, s, what)) return rc;
         launch_fold(static_cast<const float*>(ws), dx, *fold, 1, elems, s);
-        return check_launch(what);
+        if (int rc = check_launch(what)) return rc;
+        return ride.kind ? ride_alone(dx) : 0;
     }
     Plan pl = make_plan(mode, a, aligned16(a.a), aligned16(a.b));
     const size_t need = fold ? plan_ws_bytes_fold(pl) : plan_ws_bytes(pl);
@@ -1233,8 +1252,12 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     if (carry) *tail_done = 1;
     if (fold != nullptr) {
         launch_fold(static_cast<const float*>(ws), final_out, *fold, pl.splits, pl.out_elems, s);
-        return check_launch(what);
+        if (int rc = check_launch(what)) return rc;
+        return ride.kind ? ride_alone(final_out) : 0;
     }
+    if (ride.kind && pl.splits > 1 && pl.splits < 16 && (pl.out_elems & 3) == 0 && (out_c & 3) == 0 && knobs().no_bn_ride != 2)
+        // ONE launch sums the slabs, adds the bias, stores the output and takes the batch-norm reduction over it
+        return launch_bn_ride(ride, RowSource{static_cast<const float*>(ws), final_out, bias, pl.out_elems, pl.splits}, s, what);
     if (pl.splits >= 16 && (pl.out_elems & 3) == 0) {
         const long n4 = pl.out_elems >> 2;
         const int own = (int)((n4 + 15) / 16);
@@ -1259,7 +1282,7 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
         if (int rc = check_launch(what)) return rc;
         if (job.blocks > 0) *tail_done = 1;
     }
-    return 0;
+    return ride.kind ? ride_alone(final_out) : 0;
 }
 
 size_t igemm_ws_bytes(int mode, IgemmArgs a) {

@@ -10,6 +10,7 @@
 // (2) Chan merge of the partials, moving-average update, (3) normalise + affine + activation
 // (+ residual).  Backward: (1) per-block sums of dz and dz*xhat, (2) merge, dgamma/dbeta, (3) dx.
 #include "common.h"
+#include "bn_tile.h"
 
 #include <cstdint>
 #include <initializer_list>
@@ -594,11 +595,26 @@ static bool fused_bn_ok(int rows, int c, const void* p0, const void* p1, const v
 // of the same grid position read in the first (same XCD: they come out of its L2).  The partials are merged as
 // division-free sums about the first block's mean; the row block count is kept small (<= 256 workgroups per launch)
 // so that the merge is a few loads per thread.
-struct TileBn {
-    int groups, rows, c;
-    int nb;    // row blocks per group
-    int rpb;   // rows per block
-};
+//
+// The rows of the first launch may come from a contraction's split-K slabs instead of a finished tensor (RowSource):
+// the launch then sums the slabs, adds the bias, stores the finished row AND takes its statistics, i.e. it replaces
+// the contraction's slab reduction launch and the statistics launch.  The sums are taken in the order the separate
+// launches take them: same bits.
+//
+// Channel quad of one row.  KIND 0: from the finished tensor `t`; 1: summed over the slabs (+ bias) and, if `store`,
+// stored to src.out.  i4 = float4 index of the quad in the flat [groups * rows][c] tensor, q = its quad within the row.
+template <int KIND>
+__device__ __forceinline__ float4 row_quad(const RowSource& src, const float4* __restrict__ t, long i4, int q, bool store) {
+    if (KIND == 0) return t[i4];
+    const long stride4 = src.slab_elems >> 2;
+    const float4* sp = reinterpret_cast<const float4*>(src.slabs) + i4;
+    float4 v = sp[0];
+#pragma unroll 4
+    for (int k = 1; k < src.splits; ++k) v = f4_add(v, sp[(long)k * stride4]);
+    if (src.bias) v = f4_add(v, reinterpret_cast<const float4*>(src.bias)[q]);
+    if (store) reinterpret_cast<float4*>(src.out)[i4] = v;
+    return v;
+}
 
 // {sum pa', sum pb'} over the nb partials of group `grp` for the thread's channel quad; every thread of the workgroup
 // must call it.  MOMENTS: partials are {mean, m2} of n rows and the sums are {n d, m2 + n d^2}, d = mean - shift.
@@ -656,18 +672,22 @@ __device__ __forceinline__ void store_partial_quad(float2* partial, long idx, fl
 }
 
 // grid (nb, c / 64, groups); thread = (row lane 0..15, channel quad 0..15)
-__global__ __launch_bounds__(256) void bn_tile_stats_kernel(const float* __restrict__ x, float2* __restrict__ partial, TileBn s) {
+template <int KIND>
+__global__ __launch_bounds__(256) void bn_tile_stats_kernel(const float* __restrict__ x, float2* __restrict__ partial, TileBn s,
+                                                            const RowSource src) {
     __shared__ float4 red[2][256];
     const int quad = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int rb = blockIdx.x, ch0 = blockIdx.y * 64, grp = blockIdx.z;
-    const int c4 = s.c >> 2;
+    const int c4 = s.c >> 2, q = (ch0 >> 2) + quad;
     const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
-    const float4* xp = reinterpret_cast<const float4*>(x + ((long)grp * s.rows) * s.c + ch0) + quad;
-    const float4 shift = xp[(long)r0 * c4];
+    const long rowg0 = (long)grp * s.rows;
+    const float4* t = reinterpret_cast<const float4*>(x);
+    // (every row lane forms the block's first row itself; only the loop below stores rows)
+    const float4 shift = row_quad<KIND>(src, t, (rowg0 + r0) * c4 + q, q, false);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 16) {
-        const float4 d = f4_sub(xp[(long)r * c4], shift);
+        const float4 d = f4_sub(row_quad<KIND>(src, t, (rowg0 + r) * c4 + q, q, true), shift);
         s1 = f4_add(s1, d);
         s2 = f4_fma(d, d, s2);
     }
@@ -776,13 +796,17 @@ __device__ __forceinline__ float4 dz4(float4 xv, float4 dv, float4 mu, float4 rs
     return dz;
 }
 
-template <int ACT>
-__device__ __forceinline__ void tile_bn_bwd_sum_rows(const float4* xp, const float4* dp, int r0, int r1, int rl, int c4, float4 mu,
-                                                     float4 rs, float4 ga, float4 be, float act_param, float4& s0, float4& s1) {
+// (dp = the float4 view of dy, or unused when the rows of dy come from slabs; base4 = float4 index of row 0 of the
+// group for this thread's quad q)
+template <int ACT, int KIND>
+__device__ __forceinline__ void tile_bn_bwd_sum_rows(const float4* xp, const float4* dp, const RowSource& src, long base4,
+                                                     int q, int r0, int r1, int rl, int c4, float4 mu, float4 rs,
+                                                     float4 ga, float4 be, float act_param, float4& s0, float4& s1) {
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 16) {
         float4 xh;
-        const float4 dz = dz4<ACT>(xp[(long)r * c4], dp[(long)r * c4], mu, rs, ga, be, act_param, xh);
+        const float4 dv = row_quad<KIND>(src, dp, base4 + (long)r * c4, q, true);
+        const float4 dz = dz4<ACT>(xp[(long)r * c4], dv, mu, rs, ga, be, act_param, xh);
         s0 = f4_add(s0, dz);
         s1 = f4_fma(dz, xh, s1);
     }
@@ -791,7 +815,7 @@ __device__ __forceinline__ void tile_bn_bwd_sum_rows(const float4* xp, const flo
 template <int ACT>
 __device__ __forceinline__ void tile_bn_bwd_apply_rows(const float4* xp, const float4* dp, float4* op, int r0, int r1, int rl,
                                                        int c4, float4 mu, float4 rs, float4 ga, float4 be, float act_param,
-                                                       float4 a0, float4 a1, float inv_rows) {
+                                                       float4 a0, float4 a1, float inv_rows, float4& colsum) {
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 16) {
         float4 xh, o;
@@ -801,13 +825,16 @@ __device__ __forceinline__ void tile_bn_bwd_apply_rows(const float4* xp, const f
         o.z = ga.z * rs.z * (dz.z - a0.z * inv_rows - xh.z * (a1.z * inv_rows));
         o.w = ga.w * rs.w * (dz.w - a0.w * inv_rows - xh.w * (a1.w * inv_rows));
         op[(long)r * c4] = o;
+        colsum = f4_add(colsum, o);
     }
 }
 
+template <int KIND>
 __global__ __launch_bounds__(256) void bn_tile_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               float2* __restrict__ partial, TileBn s, int act, float act_param) {
+                                                               float2* __restrict__ partial, TileBn s, int act, float act_param,
+                                                               const RowSource src) {
     __shared__ float4 red[2][256];
     const int quad = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int rb = blockIdx.x, ch0 = blockIdx.y * 64, grp = blockIdx.z;
@@ -815,12 +842,12 @@ __global__ __launch_bounds__(256) void bn_tile_bwd_sums_kernel(const float* __re
     const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
     const long base = ((long)grp * s.rows) * c4 + q;
     const float4* xp = reinterpret_cast<const float4*>(x) + base;
-    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+    const float4* dp = reinterpret_cast<const float4*>(dy);
     const float4 mu = reinterpret_cast<const float4*>(mean + (long)grp * s.c)[q];
     const float4 rs = reinterpret_cast<const float4*>(rstd + (long)grp * s.c)[q];
     const float4 ga = reinterpret_cast<const float4*>(gamma)[q], be = reinterpret_cast<const float4*>(beta)[q];
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    GAN_ACT_DISPATCH(act, (tile_bn_bwd_sum_rows<ACT>(xp, dp, r0, r1, rl, c4, mu, rs, ga, be, act_param, s0, s1)));
+    GAN_ACT_DISPATCH(act, (tile_bn_bwd_sum_rows<ACT, KIND>(xp, dp, src, base, q, r0, r1, rl, c4, mu, rs, ga, be, act_param, s0, s1)));
     red[0][threadIdx.x] = s0;
     red[1][threadIdx.x] = s1;
     __syncthreads();
@@ -838,7 +865,8 @@ __global__ __launch_bounds__(256) void bn_tile_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float2* __restrict__ partial, float* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int accumulate, TileBn s, int act, float act_param) {
+                                                                int accumulate, TileBn s, int act, float act_param,
+                                                                float* __restrict__ colsum_partial) {
     __shared__ float4 red[2][256];
     const int quad = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int rb = blockIdx.x, ch0 = blockIdx.y * 64, grp = blockIdx.z;
@@ -869,8 +897,18 @@ __global__ __launch_bounds__(256) void bn_tile_bwd_apply_kernel(const float* __r
     const float4* xp = reinterpret_cast<const float4*>(x) + base;
     const float4* dp = reinterpret_cast<const float4*>(dy) + base;
     float4* op = reinterpret_cast<float4*>(dx) + base;
+    float4 cs = zero;
     GAN_ACT_DISPATCH(act, (tile_bn_bwd_apply_rows<ACT>(xp, dp, op, r0, r1, rl, c4, mu, rs, ga, be, act_param, a0, a1,
-                                                       1.0f / (float)s.rows)));
+                                                       1.0f / (float)s.rows, cs)));
+    if (colsum_partial == nullptr) return;      // (uniform over the launch)
+    // the column sum of the rows this workgroup stored: first stage of the bias gradient of the layer in front
+    __syncthreads();
+    red[0][threadIdx.x] = cs;
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < 16; ++j) cs = f4_add(cs, red[0][quad + 16 * j]);
+        reinterpret_cast<float4*>(colsum_partial + ((long)grp * s.nb + rb) * s.c)[q] = cs;
+    }
 }
 
 // The two-launch plan of a tensor, or false.
@@ -901,6 +939,42 @@ static int grid_for(long work_items) {
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
+}
+
+static RowSource tensor_rows() { return RowSource{nullptr, nullptr, nullptr, 0, 0}; }
+
+BnRide& pending_bn_ride() {
+    static thread_local BnRide r = BnRide{0, nullptr, TileBn{0, 0, 0, 0, 0}, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f};
+    return r;
+}
+
+bool bn_ride_plan(int groups, int rows, int c, bool backward, TileBn* s) {
+    if (knobs().three_launch_bn) return false;
+    if (backward) return tile_bn_plan(groups, rows, c, *s, groups > 1 ? 256 : kFusedMaxRows + 1);
+    return tile_bn_plan(groups, rows, c, *s);
+}
+
+int launch_bn_ride(const BnRide& r, const RowSource& src, hipStream_t st, const char* what) {
+    const TileBn& s = r.s;
+    const int kind = src.slabs == nullptr ? 0 : 1;
+    GAN_CHECK_ARG(r.partial != nullptr && src.out != nullptr, "%s: batch-norm reduction without a target", what);
+    GAN_CHECK_ARG(all16({src.slabs, src.out, src.bias, r.partial, r.x, r.gamma, r.beta, r.mean, r.rstd}) &&
+                  (kind == 0 || (src.slab_elems & 3) == 0),
+                  "%s: the fused batch-norm reduction needs 16-byte aligned tensors", what);
+    const dim3 grid(s.nb, s.c / 64, s.groups);
+    if (r.kind == 1) {
+        if (kind == 0) hipLaunchKernelGGL(bn_tile_stats_kernel<0>, grid, dim3(256), 0, st, (const float*)src.out, r.partial, s, src);
+        else hipLaunchKernelGGL(bn_tile_stats_kernel<1>, grid, dim3(256), 0, st, (const float*)nullptr, r.partial, s, src);
+    } else {
+        GAN_CHECK_ARG(r.x && r.gamma && r.beta && r.mean && r.rstd, "%s: batch-norm backward sums: NULL tensor", what);
+        if (kind == 0)
+            hipLaunchKernelGGL(bn_tile_bwd_sums_kernel<0>, grid, dim3(256), 0, st, r.x, (const float*)src.out, r.gamma, r.beta, r.mean,
+                               r.rstd, r.partial, s, r.act, r.act_param, src);
+        else
+            hipLaunchKernelGGL(bn_tile_bwd_sums_kernel<1>, grid, dim3(256), 0, st, r.x, (const float*)nullptr, r.gamma, r.beta, r.mean,
+                               r.rstd, r.partial, s, r.act, r.act_param, src);
+    }
+    return check_launch(what);
 }
 
 size_t bn_ws_bytes(int groups, int rows, int c) {
@@ -955,7 +1029,7 @@ extern "C" int gan_bn_fwd_train(const float* x, const float* gamma, const float*
         if (tile_bn_plan(groups, rows, c, ts) &&
             all16({x, y, residual, save_mean, save_rstd, gamma, beta, moving_mean, moving_var, ws})) {
             const dim3 grid(ts.nb, c / 64, groups);
-            hipLaunchKernelGGL(bn_tile_stats_kernel, grid, dim3(256), 0, st, x, partial, ts);
+            hipLaunchKernelGGL(bn_tile_stats_kernel<0>, grid, dim3(256), 0, st, x, partial, ts, tensor_rows());
             hipLaunchKernelGGL(bn_tile_apply_kernel, grid, dim3(256), 0, st, x, gamma, beta, moving_mean, moving_var, residual, y,
                                save_mean, save_rstd, (const float2*)partial, ts, eps, momentum, unbiased_moving_var, act, act_param);
             return check_launch("gan_bn_fwd_train");
@@ -1062,6 +1136,59 @@ extern "C" int gan_bn_moving_update_multi(const gan_bn_moving_job* jobs, int cou
     return check_launch("gan_bn_moving_update_multi");
 }
 
+// ---------------------------------------------------------------------------- batch norm around a contraction's launches
+extern "C" int gan_bn_tile_blocks(int groups, int rows, int c, int backward) {
+    if (groups <= 0 || rows <= 0 || c <= 0 || groups > 65535) return 0;
+    TileBn ts;
+    if (knobs().no_bn_ride == 1) return 0;
+    return bn_ride_plan(groups, rows, c, backward != 0, &ts) ? ts.nb : 0;
+}
+
+extern "C" int gan_bn_fwd_train_from_stats(const float* x, const float* gamma, const float* beta, float* moving_mean,
+                                           float* moving_var, const float* residual, float* y, float* save_mean,
+                                           float* save_rstd, int groups, int rows, int c, float eps, float momentum,
+                                           int unbiased_moving_var, int act, float act_param, const float* bn_partial,
+                                           gan_stream_t stream) {
+    const char* what = "gan_bn_fwd_train_from_stats";
+    if (int rc = bn_args_check(what, groups, rows, c, act)) return rc;
+    GAN_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && bn_partial, "%s: NULL tensor", what);
+    GAN_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "%s: moving_mean and moving_var must be given together", what);
+    TileBn ts;
+    GAN_CHECK_ARG(bn_ride_plan(groups, rows, c, false, &ts), "%s: no block statistics exist for %d x %d x %d (gan_bn_tile_blocks "
+                  "reports 0): use gan_bn_fwd_train", what, groups, rows, c);
+    GAN_CHECK_ARG(all16({x, y, residual, save_mean, save_rstd, gamma, beta, moving_mean, moving_var, bn_partial}),
+                  "%s: tensors must be 16-byte aligned", what);
+    const dim3 grid(ts.nb, c / 64, groups);
+    hipLaunchKernelGGL(bn_tile_apply_kernel, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, moving_mean, moving_var, residual,
+                       y, save_mean, save_rstd, reinterpret_cast<const float2*>(bn_partial), ts, eps, momentum, unbiased_moving_var,
+                       act, act_param);
+    return check_launch(what);
+}
+
+extern "C" int gan_bn_bwd_tiled(const float* x, const float* gamma, const float* beta, const float* save_mean,
+                                const float* save_rstd, const float* dy, float* dx, float* dgamma, float* dbeta,
+                                int accumulate, int groups, int rows, int c, int act, float act_param, float* sums_partial,
+                                int sums_ready, float* colsum_partial, gan_stream_t stream) {
+    const char* what = "gan_bn_bwd_tiled";
+    if (int rc = bn_args_check(what, groups, rows, c, act)) return rc;
+    GAN_CHECK_ARG(x && gamma && beta && save_mean && save_rstd && dy && sums_partial, "%s: NULL tensor", what);
+    GAN_CHECK_ARG(colsum_partial == nullptr || dx != nullptr, "%s: column sums are those of dx", what);
+    TileBn ts;
+    GAN_CHECK_ARG(bn_ride_plan(groups, rows, c, true, &ts), "%s: no block decomposition exists for %d x %d x %d (gan_bn_tile_blocks "
+                  "reports 0): use gan_bn_bwd", what, groups, rows, c);
+    GAN_CHECK_ARG(all16({x, dy, dx, save_mean, save_rstd, gamma, beta, dgamma, dbeta, sums_partial, colsum_partial}),
+                  "%s: tensors must be 16-byte aligned", what);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(ts.nb, c / 64, groups);
+    float2* partial = reinterpret_cast<float2*>(sums_partial);
+    if (!sums_ready)
+        hipLaunchKernelGGL(bn_tile_bwd_sums_kernel<0>, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, partial, ts,
+                           act, act_param, tensor_rows());
+    hipLaunchKernelGGL(bn_tile_bwd_apply_kernel, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd,
+                       (const float2*)partial, dx, dgamma, dbeta, accumulate, ts, act, act_param, colsum_partial);
+    return check_launch(what);
+}
+
 extern "C" int gan_bn_fwd_eval(const float* x, const float* gamma, const float* beta, const float* moving_mean,
                                const float* moving_var, float* y, int rows, int c, float eps, int act,
                                float act_param, gan_stream_t stream) {
@@ -1096,10 +1223,10 @@ extern "C" int gan_bn_bwd(const float* x, const float* gamma, const float* beta,
         if (tile_bn_plan(groups, rows, c, ts, groups > 1 ? 256 : kFusedMaxRows + 1) &&
             all16({x, dy, dx, save_mean, save_rstd, gamma, beta, dgamma, dbeta, ws})) {
             const dim3 grid(ts.nb, c / 64, groups);
-            hipLaunchKernelGGL(bn_tile_bwd_sums_kernel, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, partial, ts,
-                               act, act_param);
+            hipLaunchKernelGGL(bn_tile_bwd_sums_kernel<0>, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, partial,
+                               ts, act, act_param, tensor_rows());
             hipLaunchKernelGGL(bn_tile_bwd_apply_kernel, grid, dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd,
-                               (const float2*)partial, dx, dgamma, dbeta, accumulate, ts, act, act_param);
+                               (const float2*)partial, dx, dgamma, dbeta, accumulate, ts, act, act_param, (float*)nullptr);
             return check_launch("gan_bn_bwd");
         }
     }

@@ -26,11 +26,11 @@ def discriminator(image, options, reuse=False, name="discriminator"):
 
         h0 = conv2d(image, options.df_dim, name='d_h0_conv', act='lrelu')
         # -> [n, 128, 128, df_dim]
-        h1 = d_bn1(conv2d(h0, options.df_dim * 2, name='d_h1_conv'), act='lrelu')
+        h1 = d_bn1(conv2d(h0, options.df_dim * 2, name='d_h1_conv', norm_groups=1), act='lrelu')
         # -> [n, 64, 64, 2 df_dim]
-        h2 = d_bn2(conv2d(h1, options.df_dim * 4, name='d_h2_conv'), act='lrelu')
+        h2 = d_bn2(conv2d(h1, options.df_dim * 4, name='d_h2_conv', norm_groups=1), act='lrelu')
         # -> [n, 32, 32, 4 df_dim]
-        h3 = d_bn3(conv2d(h2, options.df_dim * 8, d_h=1, d_w=1, name='d_h3_conv'), act='lrelu')
+        h3 = d_bn3(conv2d(h2, options.df_dim * 8, d_h=1, d_w=1, name='d_h3_conv', norm_groups=1), act='lrelu')
         # -> [n, 32, 32, 8 df_dim] (stride 1)
         h4 = conv2d(h3, 1, d_h=1, d_w=1, name='d_h3_pred')
         # -> [n, 32, 32, 1]: one logit per patch
@@ -57,9 +57,9 @@ def generator_resnet(image, options, reuse=False, name="generator"):
             # tf.pad(x, REFLECT by p) + VALID conv (cyclegan_module.py:106-109): the padding is folded into the
             # convolution's gather (padding='REFLECT'), no padded copy is written
             assert s == 1 and p * 2 + 1 == ks
-            y = resBN1(conv2d(x, dim, ks, ks, s, s, padding='REFLECT', name=name + '_c1'), act='relu')
+            y = resBN1(conv2d(x, dim, ks, ks, s, s, padding='REFLECT', name=name + '_c1', norm_groups=1), act='relu')
             # resBN2(...) + x, the residual add fused into the normalisation kernel
-            return resBN2(conv2d(y, dim, ks, ks, s, s, padding='REFLECT', name=name + '_c2'), residual=skip)
+            return resBN2(conv2d(y, dim, ks, ks, s, s, padding='REFLECT', name=name + '_c2', norm_groups=1), residual=skip)
 
         g_e1_bn = batch_norm(name='g_e1_bn')
         g_e2_bn = batch_norm(name='g_e2_bn')
@@ -72,19 +72,19 @@ def generator_resnet(image, options, reuse=False, name="generator"):
         s2 = int(s / 2)
         # the fast-neural-style layout the reference cites (cyclegan_module.py:121-122): 7x7 stem, two stride-2
         # convs down, nine residual blocks, two stride-2 transposed convs up, 7x7 head
-        c1 = g_e1_bn(conv2d(image, options.gf_dim, 7, 7, 1, 1, padding='REFLECT', name='g_e1_c'), act='relu')
-        c2 = g_e2_bn(conv2d(c1, options.gf_dim * 2, 3, 3, 2, 2, name='g_e2_c'), act='relu')
-        c3 = g_e3_bn(conv2d(c2, options.gf_dim * 4, 3, 3, 2, 2, name='g_e3_c'), act='relu')
+        c1 = g_e1_bn(conv2d(image, options.gf_dim, 7, 7, 1, 1, padding='REFLECT', name='g_e1_c', norm_groups=1), act='relu')
+        c2 = g_e2_bn(conv2d(c1, options.gf_dim * 2, 3, 3, 2, 2, name='g_e2_c', norm_groups=1), act='relu')
+        c3 = g_e3_bn(conv2d(c2, options.gf_dim * 4, 3, 3, 2, 2, name='g_e3_c', norm_groups=1), act='relu')
         # nine residual blocks
         r = c3
         for i in range(1, 10):
             r = residule_block(r, options.gf_dim * 4, name='g_r%d' % i)
 
-        d1 = deconv2d(r, [options.batch_size, s2, s2, options.gf_dim * 2], 3, 3, 2, 2, name='g_d1_dc')
+        d1 = deconv2d(r, [options.batch_size, s2, s2, options.gf_dim * 2], 3, 3, 2, 2, name='g_d1_dc', norm_groups=1)
         d1 = g_d1_bn(d1, act='relu')
-        d2 = deconv2d(d1, [options.batch_size, s, s, options.gf_dim], 3, 3, 2, 2, name='g_d2_dc')
+        d2 = deconv2d(d1, [options.batch_size, s, s, options.gf_dim], 3, 3, 2, 2, name='g_d2_dc', norm_groups=1)
         d2 = g_d2_bn(d2, act='relu')
-        pred = conv2d(d2, options.output_c_dim, 7, 7, 1, 1, padding='REFLECT', name='g_pred_c')
+        pred = conv2d(d2, options.output_c_dim, 7, 7, 1, 1, padding='REFLECT', name='g_pred_c', norm_groups=1)
         pred = g_pred_bn(pred, act='tanh')
 
         return pred

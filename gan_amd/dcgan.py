@@ -146,17 +146,17 @@ class DCGAN(object):
                 scope.reuse_variables()
             if not self.y_dim:
                 h0 = conv2d(image, self.df_dim, name='d_h0_conv', act='lrelu')
-                h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)
-                h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)
+                h1 = self.d_bn1(conv2d(h0, self.df_dim * 2, name='d_h1_conv', norm_groups=passes), act='lrelu', passes=passes)
+                h2 = self.d_bn2(conv2d(h1, self.df_dim * 4, name='d_h2_conv', norm_groups=passes), act='lrelu', passes=passes)
                 self._note_d_boundary(h2)           # the layers after it own the early part of the d group
-                h3 = self.d_bn3(conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu', passes=passes)
+                h3 = self.d_bn3(conv2d(h2, self.df_dim * 8, name='d_h3_conv', norm_groups=passes), act='lrelu', passes=passes)
                 h4 = linear(h3.reshape(bs, -1), 1, 'd_h3_lin')
                 return (_sigmoid_value(h4) if with_prob else None), h4
             yb = y.reshape(bs, 1, 1, self.y_dim)
             x = conv_cond_concat(image, yb)
             h0 = conv2d(x, self.c_dim + self.y_dim, name='d_h0_conv', act='lrelu')
             h0 = conv_cond_concat(h0, yb)
-            h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv'), act='lrelu', passes=passes)
+            h1 = self.d_bn1(conv2d(h0, self.df_dim + self.y_dim, name='d_h1_conv', norm_groups=passes), act='lrelu', passes=passes)
             h1 = h1.reshape(bs, -1)
             h1 = concat([h1, y], 1)
             self._note_d_boundary(h1)
@@ -171,6 +171,7 @@ class DCGAN(object):
             if not train:
                 scope.reuse_variables()
             bs = self.batch_size
+            ng = 1 if train else None           # the deconvs feed training-mode batch norms of one group
             if not self.y_dim:
                 # spatial sizes of the five stages, halving with ceil (dcgan.py:357-361)
                 s_h, s_w = self.output_height, self.output_width
@@ -180,12 +181,15 @@ class DCGAN(object):
                 self.t_z_, self.h0_w, self.h0_b = linear(z, self.gf_dim * 8 * s_h16 * s_w16, 'g_h0_lin', with_w=True)
                 self.h0 = self.t_z_.reshape(-1, s_h16, s_w16, self.gf_dim * 8)
                 h0 = self.g_bn0(self.h0, train=train, act='relu')
-                self.h1, self.h1_w, self.h1_b = deconv2d(h0, [bs, s_h8, s_w8, self.gf_dim * 4], name='g_h1', with_w=True)
+                self.h1, self.h1_w, self.h1_b = deconv2d(h0, [bs, s_h8, s_w8, self.gf_dim * 4], name='g_h1', with_w=True,
+                                                           norm_groups=ng)
                 h1 = self.g_bn1(self.h1, train=train, act='relu')
                 self._g_bound = h1                  # the layers after it own the early part of the g group
-                h2, self.h2_w, self.h2_b = deconv2d(h1, [bs, s_h4, s_w4, self.gf_dim * 2], name='g_h2', with_w=True)
+                h2, self.h2_w, self.h2_b = deconv2d(h1, [bs, s_h4, s_w4, self.gf_dim * 2], name='g_h2', with_w=True,
+                                                      norm_groups=ng)
                 h2 = self.g_bn2(h2, train=train, act='relu')
-                h3, self.h3_w, self.h3_b = deconv2d(h2, [bs, s_h2, s_w2, self.gf_dim * 1], name='g_h3', with_w=True)
+                h3, self.h3_w, self.h3_b = deconv2d(h2, [bs, s_h2, s_w2, self.gf_dim * 1], name='g_h3', with_w=True,
+                                                      norm_groups=ng)
                 h3 = self.g_bn3(h3, train=train, act='relu')
                 h4, self.h4_w, self.h4_b = deconv2d(h3, [bs, s_h, s_w, self.c_dim], name='g_h4', with_w=True, act='tanh')
                 return h4                       # tanh(h4) of dcgan.py:385, applied in the deconv's epilogue
@@ -200,7 +204,7 @@ class DCGAN(object):
             h1 = h1.reshape(bs, s_h4, s_w4, self.gf_dim * 2)
             h1 = conv_cond_concat(h1, yb)
             self._g_bound = h1
-            h2 = self.g_bn2(deconv2d(h1, [bs, s_h2, s_w2, self.gf_dim * 2], name='g_h2'), train=train, act='relu')
+            h2 = self.g_bn2(deconv2d(h1, [bs, s_h2, s_w2, self.gf_dim * 2], name='g_h2', norm_groups=ng), train=train, act='relu')
             h2 = conv_cond_concat(h2, yb)
             return deconv2d(h2, [bs, s_h, s_w, self.c_dim], name='g_h3', act='sigmoid')
 

@@ -131,6 +131,21 @@ def _bn_ws(groups, rows, c):
     return _lib.workspace(n)
 
 
+# which batch-norm reductions ride on neighbouring contraction launches (all by default; tests and measurements switch
+# them one by one): forward statistics, backward sums, column sums for the bias gradient of the layer in front
+RIDE_PARTS = {'stats': True, 'sums': True, 'colsum': True}
+
+
+def _tile_blocks(groups, rows, c, backward):
+    """Row blocks per group of the two-launch batch norm for this shape (0: the shape is served by other kernels and no
+    reduction can ride on a neighbouring contraction)."""
+    key = ('t', groups, rows, c, backward)
+    n = _ws_cache.get(key)
+    if n is None:
+        n = _ws_cache[key] = int(lib.gan_bn_tile_blocks(groups, rows, c, backward))
+    return n
+
+
 def _dense(x):
     if x.dtype != torch.float32:
         raise TypeError("expected a float32 tensor, got %s" % x.dtype)
@@ -153,6 +168,80 @@ class _ActToken(object):
 
     def note_gated(self, dx):
         self.gated = (dx, dx._version)
+
+
+class _NormToken(object):
+    """Travels with the output of a conv / deconv that feeds a training-mode batch norm (`norm_groups=`): forward, the
+    contraction leaves the norm's block statistics here; backward, the norm leaves the column sums of its input
+    gradient here for the contraction's bias gradient.  Either side falls back to its own launches when the other
+    did not deliver (shape not served, tensor replaced)."""
+    __slots__ = ('groups', 'stats', 'colsum')
+
+    def __init__(self, groups):
+        self.groups = int(groups)
+        self.stats = None         # (partial statistics, address of the tensor they describe, its version counter)
+        self.colsum = None        # (gradient tensor, its version counter, partial column sums, number of row blocks)
+
+
+class _BnToken(object):
+    """Travels with the output of a training-mode batch norm.  A conv / deconv that takes that output as its input
+    lets the launch that finishes its input gradient also take the block sums of the norm's backward pass over it."""
+    __slots__ = ('saved', 'sums')
+
+    def __init__(self):
+        self.saved = None         # (x, save_mean, save_rstd, gamma, beta, groups, rows, c, act code, act parameter)
+        self.sums = None          # (gradient tensor, its version counter, partial sums)
+
+
+def _same_tensor(t, ref, version):
+    return t.data_ptr() == ref.data_ptr() and t._version == version
+
+
+def _dgrad_with_bn_sums(op, g, dy, w, dx, in_bn, wp, wn):
+    """The input gradient dx of a conv / deconv whose input was the output of the batch norm `in_bn`, leaving that
+    norm's backward block sums with the token; False when the norm's shape has no such decomposition."""
+    bx, mean, rstd, gamma, beta, groups, rows, c, act, act_param = in_bn.saved
+    nb = _tile_blocks(groups, rows, c, 1) if RIDE_PARTS['sums'] else 0
+    if not nb or dx.numel() != groups * rows * c:
+        return False
+    partial = torch.empty(2 * groups * nb * c, dtype=torch.float32, device=dx.device)
+    saved = _lib.BnSaved(ptr(bx), ptr(gamma.data), ptr(beta.data), ptr(mean), ptr(rstd), groups, act, act_param)
+    check(lib.gan_conv_dgrad_bn_sums(op, ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ctypes.byref(saved), ptr(partial),
+                                     wp, wn, stream()))
+    in_bn.sums = (dx, dx._version, partial)
+    return True
+
+
+def _wgrad(op, plain, g, x, dy, w, b, norm_tok, wp, wn):
+    """Weight and bias gradient; the bias gradient from the column sums the batch norm behind this layer left."""
+    dw, acc = w.grad_target()
+    db, accb = b.grad_target()
+    assert acc == accb
+    cs = None
+    if norm_tok is not None:
+        cs, norm_tok.colsum = norm_tok.colsum, None
+    if cs is not None and _same_tensor(dy, cs[0], cs[1]):
+        check(lib.gan_conv_wgrad_colsum(op, ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, ptr(cs[2]), cs[3], wp, wn,
+                                        stream()))
+    else:
+        check(plain(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
+
+
+def _fwd_with_bn_stats(op, g, x, w, b, y, norm_tok, wp, wn):
+    """y = conv / deconv of x, leaving the block statistics of the batch norm that follows with the token; False when
+    that norm's shape has no such decomposition."""
+    c = y.shape[-1]
+    rows_all = y.numel() // c
+    if rows_all % norm_tok.groups:
+        return False
+    nb = _tile_blocks(norm_tok.groups, rows_all // norm_tok.groups, c, 0) if RIDE_PARTS['stats'] else 0
+    if not nb:
+        return False
+    partial = torch.empty(2 * norm_tok.groups * nb * c, dtype=torch.float32, device=y.device)
+    check(lib.gan_conv_fwd_bn_stats(op, ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), norm_tok.groups, ptr(partial),
+                                    wp, wn, stream()))
+    norm_tok.stats = (partial, y.data_ptr(), y._version)
+    return True
 
 
 def _act_spec(act, act_param, act_scale, act_shift):
@@ -185,14 +274,18 @@ def _through_own_activation(ctx, y, dy):
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, token, w, b, g, act_tok, in_tok, reflect=False):
+    def forward(ctx, x, token, w, b, g, act_tok, in_tok, reflect=False, norm_tok=None, in_bn=None):
         x = _dense(x)
         y = torch.empty((g.n, g.hs, g.ws, g.cs), dtype=torch.float32, device=x.device)
         wp, wn = _conv_ws(g)
         ctx.reflect = reflect
-        if reflect:
-            if act_tok is not None or in_tok is not None:
-                raise ValueError("conv2d: REFLECT padding does not combine with a fused activation")
+        ctx.op = _lib.OP_CONV2D_REFLECT if reflect else _lib.OP_CONV2D
+        ctx.norm_tok, ctx.in_bn = norm_tok, in_bn
+        if reflect and (act_tok is not None or in_tok is not None):
+            raise ValueError("conv2d: REFLECT padding does not combine with a fused activation")
+        if norm_tok is not None and act_tok is None and _fwd_with_bn_stats(ctx.op, g, x, w, b, y, norm_tok, wp, wn):
+            ctx.save_for_backward(x)
+        elif reflect:
             check(lib.gan_conv2d_fwd_reflect(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
             ctx.save_for_backward(x)
         elif act_tok is None:
@@ -215,15 +308,18 @@ class _Conv2dFn(torch.autograd.Function):
         dy = _dense(dy)
         wp, wn = _conv_ws(g)
         if w.wants_grad:
-            dw, acc = w.grad_target()
-            db, accb = b.grad_target()
-            assert acc == accb
-            wgrad = lib.gan_conv2d_wgrad_reflect if ctx.reflect else lib.gan_conv2d_wgrad
-            check(wgrad(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
+            _wgrad(ctx.op, lib.gan_conv2d_wgrad_reflect if ctx.reflect else lib.gan_conv2d_wgrad, g, x, dy, w, b, ctx.norm_tok,
+                   wp, wn)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if ctx.reflect:
+            if ctx.in_bn is not None and ctx.in_tok is None and ctx.reflect and g.pt == g.pl and \
+                    _dgrad_with_bn_sums(ctx.op, g, dy, w, dx, ctx.in_bn, *_reflect_dgrad_ws(g)):
+                pass
+            elif ctx.in_bn is not None and ctx.in_tok is None and not ctx.reflect and \
+                    _dgrad_with_bn_sums(ctx.op, g, dy, w, dx, ctx.in_bn, wp, wn):
+                pass
+            elif ctx.reflect:
                 # input gradient of the VALID convolution on the reflect-padded image, folded back onto the image by the
                 # kernel that sums the split-K slabs
                 if g.pt != g.pl:
@@ -237,16 +333,19 @@ class _Conv2dFn(torch.autograd.Function):
                 check(lib.gan_conv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param, scale,
                                                  shift, wp, wn, stream()))
                 ctx.in_tok.note_gated(dx)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None
 
 
 class _Deconv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, token, w, b, g, act_tok, in_tok):
+    def forward(ctx, x, token, w, b, g, act_tok, in_tok, norm_tok=None, in_bn=None):
         x = _dense(x)
         y = torch.empty((g.n, g.hb, g.wb, g.cb), dtype=torch.float32, device=x.device)
         wp, wn = _conv_ws(g)
-        if act_tok is None:
+        ctx.norm_tok, ctx.in_bn = norm_tok, in_bn
+        if norm_tok is not None and act_tok is None and _fwd_with_bn_stats(_lib.OP_DECONV2D, g, x, w, b, y, norm_tok, wp, wn):
+            ctx.save_for_backward(x)
+        elif act_tok is None:
             check(lib.gan_deconv2d_fwd(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
             ctx.save_for_backward(x)
         else:
@@ -266,21 +365,21 @@ class _Deconv2dFn(torch.autograd.Function):
         dy = _dense(dy)
         wp, wn = _conv_ws(g)
         if w.wants_grad:
-            dw, acc = w.grad_target()
-            db, accb = b.grad_target()
-            assert acc == accb
-            check(lib.gan_deconv2d_wgrad(ctypes.byref(g), ptr(x), ptr(dy), ptr(dw), ptr(db), acc, wp, wn, stream()))
+            _wgrad(_lib.OP_DECONV2D, lib.gan_deconv2d_wgrad, g, x, dy, w, b, ctx.norm_tok, wp, wn)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if ctx.in_tok is None:
+            if ctx.in_bn is not None and ctx.in_tok is None and \
+                    _dgrad_with_bn_sums(_lib.OP_DECONV2D, g, dy, w, dx, ctx.in_bn, wp, wn):
+                pass
+            elif ctx.in_tok is None:
                 check(lib.gan_deconv2d_dgrad(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), wp, wn, stream()))
             else:
                 code, param, scale, shift = ctx.in_tok.spec
                 check(lib.gan_deconv2d_dgrad_gated(ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ptr(x), code, param,
                                                    scale, shift, wp, wn, stream()))
                 ctx.in_tok.note_gated(dx)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -321,14 +420,40 @@ def _fused_act_of(t):
     return getattr(t, '_gan_act', None) if torch.is_grad_enabled() and t.requires_grad else None
 
 
+def _bn_of(t):
+    """The token of a training-mode batch norm's output (None for any other tensor)."""
+    return getattr(t, '_gan_bn', None) if torch.is_grad_enabled() and t.requires_grad else None
+
+
+def _norm_token(norm_groups, spec):
+    if norm_groups is None:
+        return None
+    if spec is not None:
+        raise ValueError("norm_groups= (a batch norm follows) does not combine with a fused activation")
+    return _NormToken(norm_groups)
+
+
+def _hand_over(y, act_tok, norm_tok):
+    if act_tok is not None:
+        y._gan_act = act_tok
+    if norm_tok is not None:
+        y._gan_norm = norm_tok
+        if norm_tok.stats is not None:      # (the version counter as the consumer will see it)
+            norm_tok.stats = (norm_tok.stats[0], y.data_ptr(), y._version)
+    return y
+
+
 def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding='SAME', name="conv2d", *,
-           act=None, act_param=0.2, act_scale=1.0, act_shift=0.0):
+           act=None, act_param=0.2, act_scale=1.0, act_shift=0.0, norm_groups=None):
     """ops.py:64-74: w [k_h,k_w,Cin,Cout] truncated-normal, biases zeros, tf.nn.conv2d + bias_add.
 
     Extension (keyword-only; the default is the reference's op): `act` fuses the activation the caller would
     apply to the result -- lrelu(conv2d(..)) of dcgan.py:328 is conv2d(.., act='lrelu') -- into the store, as
     act(conv + bias) * act_scale + act_shift.  Such an output must feed ONE consumer; when that consumer is a
-    conv2d / deconv2d, its input-gradient pass also applies this activation's derivative."""
+    conv2d / deconv2d, its input-gradient pass also applies this activation's derivative.
+    `norm_groups` = k says that the result goes straight into a training-mode batch_norm(.., passes=k) (k = batch size
+    for instance_norm): the launch that finishes the convolution then takes that norm's statistics too.  Values are
+    unchanged, and a batch norm that does not follow after all is harmless."""
     st = V.default_store()
     n, h, w_, cin = input_.shape
     with st.variable_scope(name):
@@ -341,18 +466,18 @@ def conv2d(input_, output_dim, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, padding=
     tok = _ActToken(spec) if spec is not None else None
     if padding == 'REFLECT' and autotune.enabled():
         autotune.tune_geometry(_lib.conv_geom(g.n, g.hb + 2 * g.pt, g.wb + 2 * g.pl, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, 1, 1, 0, 0))
+    ntok = _norm_token(norm_groups, spec)
     y = _Conv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_),
-                        padding == 'REFLECT')
-    if tok is not None:
-        y._gan_act = tok
-    return y
+                        padding == 'REFLECT', ntok, _bn_of(input_))
+    return _hand_over(y, tok, ntok)
 
 
 def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name="deconv2d", with_w=False, *,
-             act=None, act_param=0.2, act_scale=1.0, act_shift=0.0):
+             act=None, act_param=0.2, act_scale=1.0, act_shift=0.0, norm_groups=None):
     """ops.py:76-99: w [k_h,k_w,Cout,Cin] normal, tf.nn.conv2d_transpose (SAME) + bias_add.
     `output_shape` carries the static batch size, as in the reference.  `act` ...: as for conv2d (the returned
-    tensor is then the ACTIVATED one: tanh(deconv2d(..)) of dcgan.py:385 is deconv2d(.., act='tanh'))."""
+    tensor is then the ACTIVATED one: tanh(deconv2d(..)) of dcgan.py:385 is deconv2d(.., act='tanh')); `norm_groups`: as
+    for conv2d."""
     st = V.default_store()
     n, hs, ws, cin = input_.shape
     on, oh, ow, oc = [int(v) for v in output_shape]
@@ -366,9 +491,9 @@ def deconv2d(input_, output_shape, k_h=5, k_w=5, d_h=2, d_w=2, stddev=0.02, name
         autotune.tune_geometry(g)
     spec = _act_spec(act, act_param, act_scale, act_shift)
     tok = _ActToken(spec) if spec is not None else None
-    deconv = _Deconv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_))
-    if tok is not None:
-        deconv._gan_act = tok
+    ntok = _norm_token(norm_groups, spec)
+    deconv = _hand_over(_Deconv2dFn.apply(input_, _grad_token(input_.device, w), w, biases, g, tok, _fused_act_of(input_), ntok,
+                                          _bn_of(input_)), tok, ntok)
     if with_w:
         return deconv, w, biases
     return deconv
@@ -433,19 +558,34 @@ class moving_update_log(object):
 
 class _NormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, token, gamma, beta, mm, mv, groups, eps, momentum, unbiased, act, act_param):
+    def forward(ctx, x, residual, token, gamma, beta, mm, mv, groups, eps, momentum, unbiased, act, act_param, norm_tok=None,
+                bn_tok=None):
+        stats = None
+        if norm_tok is not None:
+            stats, norm_tok.stats = norm_tok.stats, None
+            if norm_tok.groups != groups or stats is None or stats[1] != x.data_ptr() or stats[2] != x._version or \
+                    not x.is_contiguous():
+                stats = None
         x = _dense(x)
         c = x.shape[-1]
         rows = x.numel() // c // groups
         y = torch.empty_like(x)
         save_mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         save_rstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
-        wp, wn = _bn_ws(groups, rows, c)
         res = None if residual is None else _dense(residual)
-        check(lib.gan_bn_fwd_train(ptr(x), ptr(gamma.data), ptr(beta.data),
-                                   None if mm is None else ptr(mm.data), None if mv is None else ptr(mv.data),
-                                   ptr(res), ptr(y), ptr(save_mean), ptr(save_rstd), groups, rows, c,
-                                   eps, momentum, int(unbiased), act, act_param, wp, wn, stream()))
+        pmm, pmv = (None if mm is None else ptr(mm.data)), (None if mv is None else ptr(mv.data))
+        if stats is not None:      # the convolution in front left the block statistics
+            check(lib.gan_bn_fwd_train_from_stats(ptr(x), ptr(gamma.data), ptr(beta.data), pmm, pmv, ptr(res), ptr(y),
+                                                  ptr(save_mean), ptr(save_rstd), groups, rows, c, eps, momentum, int(unbiased),
+                                                  act, act_param, ptr(stats[0]), stream()))
+        else:
+            wp, wn = _bn_ws(groups, rows, c)
+            check(lib.gan_bn_fwd_train(ptr(x), ptr(gamma.data), ptr(beta.data), pmm, pmv, ptr(res), ptr(y), ptr(save_mean),
+                                       ptr(save_rstd), groups, rows, c, eps, momentum, int(unbiased), act, act_param, wp, wn,
+                                       stream()))
+        ctx.norm_tok, ctx.bn_tok = norm_tok, bn_tok
+        if bn_tok is not None:
+            bn_tok.saved = (x, save_mean, save_rstd, gamma, beta, groups, rows, c, act, act_param)
         if moving_update_log.current is not None and mm is not None and groups == 1:
             moving_update_log.current.entries.append((mm, mv, save_mean, save_rstd, rows, c, eps, momentum, unbiased))
         ctx.save_for_backward(x, save_mean, save_rstd)
@@ -466,12 +606,29 @@ class _NormFn(torch.autograd.Function):
             db, accb = beta.grad_target()
             assert acc == accb
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        if dx is not None or dg is not None:
+        sums = None
+        if ctx.bn_tok is not None:
+            sums, ctx.bn_tok.sums = ctx.bn_tok.sums, None
+        nb = _tile_blocks(groups, rows, c, 1) if (dx is not None or dg is not None) else 0
+        if nb:
+            # block sums left by the consumer's input-gradient launch (only if dy is that very tensor, untouched), and
+            # column sums of dx for the bias gradient of the conv / deconv in front
+            ready = sums is not None and _same_tensor(dy, sums[0], sums[1])
+            partial = sums[2] if ready else torch.empty(2 * groups * nb * c, dtype=torch.float32, device=x.device)
+            colsum = None
+            if dx is not None and ctx.norm_tok is not None and RIDE_PARTS['colsum']:
+                colsum = torch.empty(groups * nb * c, dtype=torch.float32, device=x.device)
+            check(lib.gan_bn_bwd_tiled(ptr(x), ptr(gamma.data), ptr(beta.data), ptr(save_mean), ptr(save_rstd), ptr(dy), ptr(dx),
+                                       ptr(dg), ptr(db), acc, groups, rows, c, act, act_param, ptr(partial), int(ready),
+                                       ptr(colsum), stream()))
+            if colsum is not None:
+                ctx.norm_tok.colsum = (dx, dx._version, colsum, groups * nb)
+        elif dx is not None or dg is not None:
             wp, wn = _bn_ws(groups, rows, c)
             check(lib.gan_bn_bwd(ptr(x), ptr(gamma.data), ptr(beta.data), ptr(save_mean), ptr(save_rstd), ptr(dy),
                                  ptr(dx), ptr(dg), ptr(db), acc, groups, rows, c, act, act_param, wp, wn, stream()))
         dres = dy if ctx.needs_input_grad[1] else None
-        return (dx, dres) + (None,) * 11
+        return (dx, dres) + (None,) * 13
 
 
 class batch_norm(object):
@@ -506,8 +663,12 @@ class batch_norm(object):
         if train:
             if x.shape[0] % passes:
                 raise ValueError("batch_norm: batch of %d does not split into %d passes" % (x.shape[0], passes))
-            return _NormFn.apply(x, residual, _grad_token(x.device, gamma), gamma, beta, mm, mv, int(passes), float(self.epsilon),
-                                 float(self.momentum), self.unbiased_moving_var, code, float(act_param))
+            btok = _BnToken()
+            y = _NormFn.apply(x, residual, _grad_token(x.device, gamma), gamma, beta, mm, mv, int(passes), float(self.epsilon),
+                              float(self.momentum), self.unbiased_moving_var, code, float(act_param),
+                              getattr(x, '_gan_norm', None), btok)
+            y._gan_bn = btok
+            return y
         if residual is not None:
             raise ValueError("batch_norm(train=False) does not take a residual")
         x = _dense(x.detach())
@@ -528,8 +689,11 @@ def instance_norm(x, name="instance_norm", epsilon=1e-5, act=None, act_param=0.2
     with st.variable_scope(name):
         beta = st.get_variable('beta', [c], V.constant_initializer(0.0))
         gamma = st.get_variable('gamma', [c], V.constant_initializer(1.0))
-    return _NormFn.apply(x, None, _grad_token(x.device, gamma), gamma, beta, None, None, int(x.shape[0]), float(epsilon),
-                         0.0, False, ACT_CODES[act], float(act_param))
+    btok = _BnToken()
+    y = _NormFn.apply(x, None, _grad_token(x.device, gamma), gamma, beta, None, None, int(x.shape[0]), float(epsilon),
+                      0.0, False, ACT_CODES[act], float(act_param), getattr(x, '_gan_norm', None), btok)
+    y._gan_bn = btok
+    return y
 
 
 # --------------------------------------------------------------------------------------------

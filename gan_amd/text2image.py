@@ -110,14 +110,15 @@ class Text2Image(object):
             h0 = z_.reshape(-1, s16, s16, self.gf_dim * 8)
             h0 = self.g_bn0(h0, train=train, act='relu')
 
-            h1 = ops.deconv2d(h0, [bs, s8, s8, self.gf_dim * 4], name='g_h1')
+            ng = 1 if train else None           # the deconvs feed training-mode batch norms of one group
+            h1 = ops.deconv2d(h0, [bs, s8, s8, self.gf_dim * 4], name='g_h1', norm_groups=ng)
             h1 = self.g_bn1(h1, train=train, act='relu')
             self._g_bound = h1                  # the layers after it own the early part of the g group
 
-            h2 = ops.deconv2d(h1, [bs, s4, s4, self.gf_dim * 2], name='g_h2')
+            h2 = ops.deconv2d(h1, [bs, s4, s4, self.gf_dim * 2], name='g_h2', norm_groups=ng)
             h2 = self.g_bn2(h2, train=train, act='relu')
 
-            h3 = ops.deconv2d(h2, [bs, s2, s2, self.gf_dim * 1], name='g_h3')
+            h3 = ops.deconv2d(h2, [bs, s2, s2, self.gf_dim * 1], name='g_h3', norm_groups=ng)
             h3 = self.g_bn3(h3, train=train, act='relu')
 
             # tf.tanh(h4)/2. + 0.5, applied in the deconv's epilogue
@@ -134,16 +135,16 @@ class Text2Image(object):
                 scope.reuse_variables()
 
             h0 = ops.conv2d(image, self.df_dim, name='d_h0_conv', act='lrelu')                                       # 32
-            h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv'), act='lrelu', passes=passes)         # 16
-            h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv'), act='lrelu', passes=passes)         # 8
+            h1 = self.d_bn1(ops.conv2d(h0, self.df_dim * 2, name='d_h1_conv', norm_groups=passes), act='lrelu', passes=passes)         # 16
+            h2 = self.d_bn2(ops.conv2d(h1, self.df_dim * 4, name='d_h2_conv', norm_groups=passes), act='lrelu', passes=passes)         # 8
             if isinstance(self._d_bound, list):
                 self._d_bound.append(h2)        # the layers after it own the early part of the d group
-            h3 = self.d_bn3(ops.conv2d(h2, self.df_dim * 8, name='d_h3_conv'), act='lrelu', passes=passes)         # 4
+            h3 = self.d_bn3(ops.conv2d(h2, self.df_dim * 8, name='d_h3_conv', norm_groups=passes), act='lrelu', passes=passes)         # 4
 
             # ADD TEXT EMBEDDING TO THE NETWORK: expand_dims x2 + tile [1,4,4,1] + concat on channels
             reduced_text_embeddings = ops.lrelu(ops.linear(t_text_embedding, self.t_dim, 'd_embedding'))
             h3_concat = ops.conv_cond_concat(h3, reduced_text_embeddings.reshape(bs, 1, 1, self.t_dim))
-            h3_new = self.d_bn4(ops.conv2d(h3_concat, self.df_dim * 8, 1, 1, 1, 1, name='d_h3_conv_new'), act='lrelu',
+            h3_new = self.d_bn4(ops.conv2d(h3_concat, self.df_dim * 8, 1, 1, 1, 1, name='d_h3_conv_new', norm_groups=passes), act='lrelu',
                                 passes=passes)                                                                     # 4
 
             h4 = ops.linear(h3_new.reshape(bs, -1), 1, 'd_h3_lin')

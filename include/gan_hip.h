@@ -187,6 +187,60 @@ int gan_bn_bwd(const float* x, const float* gamma, const float* beta, const floa
                int accumulate, int groups, int rows, int c, int act, float act_param, void* ws,
                size_t ws_bytes, gan_stream_t stream);
 
+/* ---- batch norm around a conv / deconv, with fewer launches -------------------------------------------------
+ * No counterpart in the reference (TensorFlow schedules conv2d, bias_add and batch_norm as separate ops; these
+ * entry points compute the same values): every layer of the reference's networks except the first and last is
+ * conv / deconv -> batch_norm -> activation (dcgan.py:330-333,368-380; cyclegan_module.py:21-30,106-110,126-141),
+ * and at training sizes both the contraction and the batch norm reduce in two launches -- split-K slabs then their
+ * sum; block statistics then normalise.  Here the middle two become one launch:
+ *   forward   gan_conv_fwd_bn_stats: y = op(x, w) + bias as gan_conv2d_fwd / gan_deconv2d_fwd / gan_conv2d_fwd_reflect
+ *             compute it, and the batch norm's block statistics of y in bn_partial; then
+ *             gan_bn_fwd_train_from_stats = gan_bn_fwd_train without its statistics launch.
+ *   backward  gan_conv_dgrad_bn_sums: dx = input gradient of op (as gan_conv2d_dgrad / gan_deconv2d_dgrad /
+ *             gan_conv2d_dgrad_reflect), where the op's INPUT was the output of the batch norm (+ activation) `bn`:
+ *             the block sums of that batch norm's backward over dx are left in bn_partial (the reflect variant keeps its
+ *             launch that folds the mirrored border back, so there the sums are a launch of their own); then
+ *             gan_bn_bwd_tiled(.., sums_partial = bn_partial, sums_ready = 1, ..) = gan_bn_bwd without its sums launch.
+ *   bias      gan_bn_bwd_tiled with colsum_partial != NULL also leaves the column sums of the rows of dx each of its
+ *             workgroups stored; gan_conv_wgrad_colsum = the weight gradient of the layer in front of the batch norm,
+ *             taking its bias gradient db from those instead of reading dx again in a launch of its own.
+ * All results are bit-identical to the separate entry points, except db through column-sum partials (same terms,
+ * different grouping of the fp32 sum).  `op`: GAN_OP_*.  The shapes served are those for which
+ * gan_bn_tile_blocks(groups, rows, c, backward) returns nb > 0 (channel count a multiple of 64, more than 1024 rows
+ * per group -- 256 for the backward of stacked groups; the other shapes have one-launch batch norms already):
+ * bn_partial / sums_partial hold 2 * groups * nb * c floats, colsum_partial groups * nb * c floats
+ * (colsum_blocks = groups * nb); all tensors 16-byte aligned. */
+enum { GAN_OP_CONV2D = 0, GAN_OP_DECONV2D = 1, GAN_OP_CONV2D_REFLECT = 2 };
+typedef struct gan_bn_saved {
+    const float* x;          /* the batch norm's input */
+    const float* gamma;
+    const float* beta;
+    const float* save_mean;  /* as gan_bn_fwd_train saved them */
+    const float* save_rstd;
+    int groups;
+    int act;                 /* the activation fused behind the batch norm */
+    float act_param;
+} gan_bn_saved;
+int gan_bn_tile_blocks(int groups, int rows, int c, int backward);
+int gan_conv_fwd_bn_stats(int op, const gan_conv_geom* g, const float* x, const float* w, const float* bias,
+                          float* y, int groups, float* bn_partial, void* ws, size_t ws_bytes,
+                          gan_stream_t stream);
+int gan_bn_fwd_train_from_stats(const float* x, const float* gamma, const float* beta, float* moving_mean,
+                                float* moving_var, const float* residual, float* y, float* save_mean,
+                                float* save_rstd, int groups, int rows, int c, float eps, float momentum,
+                                int unbiased_moving_var, int act, float act_param, const float* bn_partial,
+                                gan_stream_t stream);
+int gan_conv_dgrad_bn_sums(int op, const gan_conv_geom* g, const float* dy, const float* w, float* dx,
+                           const gan_bn_saved* bn, float* bn_partial, void* ws, size_t ws_bytes,
+                           gan_stream_t stream);
+int gan_bn_bwd_tiled(const float* x, const float* gamma, const float* beta, const float* save_mean,
+                     const float* save_rstd, const float* dy, float* dx, float* dgamma, float* dbeta,
+                     int accumulate, int groups, int rows, int c, int act, float act_param, float* sums_partial,
+                     int sums_ready, float* colsum_partial, gan_stream_t stream);
+int gan_conv_wgrad_colsum(int op, const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
+                          int accumulate, const float* colsum_partial, int colsum_blocks, void* ws,
+                          size_t ws_bytes, gan_stream_t stream);
+
 /* ---- stand-alone activations (ops.py:101-102; dcgan.py:334,368-385,409; text2image.py:198)
  * forward: y = act(x)*scale + shift; backward from the saved y: dx = dy*scale*act'(.) */
 int gan_act_fwd(const float* x, float* y, long n, int act, float act_param, float scale, float shift,
@@ -302,6 +356,11 @@ int gan_get_exact_f32(void);
  *   "rgb_gather"      GAN_HIP_RGB_GATHER=<0..2>  filter-row gather of the bf16 kernels for 3-channel images: 1 (default)
  *                                                forward and weight gradient, 2 weight gradient only, 0 off (those
  *                                                layers then run on the fp32 MFMA kernel)
+ *   "no_bn_ride"      GAN_HIP_NO_BN_RIDE=<1|2>   1: gan_bn_tile_blocks reports 0, so callers keep the separate batch-norm
+ *                                                launches; 2: the reductions of gan_conv_fwd_bn_stats / gan_conv_dgrad_bn_sums
+ *                                                run as launches of their own behind the contraction (bit-identical)
+ *   "no_carry"        GAN_HIP_NO_CARRY=1         the last stage of a bias gradient's column sum never rides on a contraction
+ *                                                launch that has no slab reduction (it runs as a launch of its own)
  * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe
  * against concurrent calls into the library. */
 int gan_knob_set(const char* name, int value);
