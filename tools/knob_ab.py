@@ -17,11 +17,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import bench  # noqa: E402
-from gan_amd import _lib, autotune  # noqa: E402
+from gan_amd import _lib, autotune, ops  # noqa: E402
 
 
 DEFAULTS = {"force_cfg": -1, "force_splits": 0, "no_thin": 0, "slow_gather": 0, "scalar_epilogue": 0, "three_launch_bn": 0,
-            "two_launch_bn": 1, "separate_colsum": 0, "tile_order": 0, "rgb_gather": 1, "no_carry": 0, "no_bn_ride": 0}
+            "two_launch_bn": 1, "separate_colsum": 0, "tile_order": 0, "rgb_gather": 1, "no_carry": 0, "no_bn_ride": 0,
+            "ride_parts": 7}      # (host side, gan_amd.ops.RIDE_PARTS: 1 forward statistics + 2 backward sums + 4 column sums)
 
 
 def parse(spec):
@@ -72,11 +73,14 @@ def main():
     variants = [("a", parse(args.a)), ("b", parse(args.b))]
     knobs = sorted(set(variants[0][1]) | set(variants[1][1]))
     model, batch, make_runner = build(args.model, np.random.default_rng(1000))
-    from gan_amd import ops
     runs = {}
     for name, setting in variants:
         for k in knobs:                       # a knob one variant names and the other does not: its default there
-            _lib.knob_set(k, setting.get(k, DEFAULTS[k]))
+            value = setting.get(k, DEFAULTS[k])
+            if k == "ride_parts":
+                ops.RIDE_PARTS.update({'stats': bool(value & 1), 'sums': bool(value & 2), 'colsum': bool(value & 4)})
+            else:
+                _lib.knob_set(k, value)
         ops._ws_cache.clear()
         model.train_iteration(*batch)          # eager: workspace sizes follow the plans
         torch.cuda.synchronize()

@@ -37,7 +37,7 @@ def main():
     total = sum(d[1] for d in agg.values())
     contraction = sum(d[1] for k, d in agg.items() if k.startswith(("igemm_kernel", "igemm_split_kernel", "reduce_slabs", "tprop_thin")))
     lines = ["# Kernel statistics of the timed region (%d graph replays)" % steps, "",
-             "Source: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup 2 --no-cpu-baseline`; "
+             "Source: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup 2 --no-cpu-baseline --no-exact-f32-time`; "
              "only the kernels of the %d timed replays are counted (%d launches, %.1f per iteration)."
              % (steps, steps, len(sel), len(sel) / steps), "",
              "Wall time of the region %.3f ms = %.3f ms per iteration; summed kernel time %.3f ms per iteration; "
