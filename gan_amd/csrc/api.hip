@@ -74,6 +74,7 @@ Knobs& knobs() {
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
         r.no_carry = getenv("GAN_HIP_NO_CARRY") != nullptr;
         r.no_bn_ride = env_int("GAN_HIP_NO_BN_RIDE", 0);
+        r.rgb_direct = env_int("GAN_HIP_RGB_DIRECT", 1);
         return r;
     }();
     return k;
@@ -603,6 +604,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "rgb_gather")) k.rgb_gather = value;
     else if (!strcmp(name, "no_carry")) k.no_carry = value != 0;
     else if (!strcmp(name, "no_bn_ride")) k.no_bn_ride = value;
+    else if (!strcmp(name, "rgb_direct")) k.rgb_direct = value != 0;
     else return fail("gan_knob_set: unknown knob '%s'", name);
     return 0;
 }

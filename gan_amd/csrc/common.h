@@ -41,6 +41,7 @@ struct Knobs {
     int exact_f32;      // GAN_HIP_EXACT_F32: default of gan_set_exact_f32
     int no_bn_ride;     // GAN_HIP_NO_BN_RIDE: 1 gan_bn_tile_blocks reports 0 (callers keep the separate batch-norm launches); 2 the
                         // reductions asked for run as launches of their own behind the contraction instead of riding
+    int rgb_direct;     // GAN_HIP_RGB_DIRECT: 0 keeps forward passes over 3-channel images on the general kernels
     int no_carry;       // GAN_HIP_NO_CARRY: the last stage of a bias-gradient column sum never rides on a contraction launch
 };
 Knobs& knobs();

@@ -1194,6 +1194,11 @@ int run_igemm(int mode, IgemmArgs a, int out_c, void* ws, size_t ws_bytes, hipSt
     };
     if (mode == MODE_TPROP) build_classes(a.g, a);
     else a.ncls = 1;
+    if (mode == MODE_FPROP && knobs().rgb_direct && knobs().force_cfg < 0 && !exact_f32() && rgb_fprop_ok(a)) {
+        // first layer over a 3-channel image: one pass, no slice pipeline, no slabs (rgb.hip)
+        if (int rc = run_rgb_fprop(a, s, what)) return rc;
+        return ride.kind ? ride_alone(a.out) : 0;
+    }
     if (mode == MODE_TPROP && thin_tprop_ok(a)) {
         if (fold == nullptr) {
             if (int rc = run_thin_tprop(a, s, what)) return rc;

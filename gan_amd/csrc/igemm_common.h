@@ -115,6 +115,10 @@ __device__ __forceinline__ int reflect_at(int i, int n) { return i < 0 ? -i : (i
 // translation unit (igemm_split_tu.hip).  cfg: p0 {4: 128x128, 7: the same with two k groups per workgroup},
 // p1 {5: 128x64, 8}, p2 {6: 64x64, 9: 128x32 (not TPROP)}.  slow_gather: general gather arithmetic even where the
 // cheap one applies (test knob).
+// rgb.hip: forward pass over a 3-channel image without a slice pipeline
+bool rgb_fprop_ok(const IgemmArgs& a);
+int run_rgb_fprop(const IgemmArgs& a, hipStream_t s, const char* what);
+
 #define GAN_DECLARE_SPLIT(m, p) void launch_split_m##m##_p##p(const IgemmArgs& a, int cfg, bool slow_gather, dim3 grid, hipStream_t s)
 GAN_DECLARE_SPLIT(0, 0); GAN_DECLARE_SPLIT(0, 1); GAN_DECLARE_SPLIT(0, 2);
 GAN_DECLARE_SPLIT(1, 0); GAN_DECLARE_SPLIT(1, 1); GAN_DECLARE_SPLIT(1, 2);

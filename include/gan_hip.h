@@ -359,6 +359,9 @@ int gan_get_exact_f32(void);
  *   "no_bn_ride"      GAN_HIP_NO_BN_RIDE=<1|2>   1: gan_bn_tile_blocks reports 0, so callers keep the separate batch-norm
  *                                                launches; 2: the reductions of gan_conv_fwd_bn_stats / gan_conv_dgrad_bn_sums
  *                                                run as launches of their own behind the contraction (bit-identical)
+ *   "rgb_direct"      GAN_HIP_RGB_DIRECT=0       forward passes over 3-channel images (5-row filters of up to 5 columns, output
+ *                                                channels a multiple of 64) stay on the general kernels instead of the
+ *                                                one-pass kernel
  *   "no_carry"        GAN_HIP_NO_CARRY=1         the last stage of a bias gradient's column sum never rides on a contraction
  *                                                launch that has no slab reduction (it runs as a launch of its own)
  * Changing force_cfg / force_splits changes the workspace sizes the queries report.  Not thread safe

@@ -924,3 +924,57 @@ def test_weight_and_bias_gradient_of_unaligned_views(L):
     for dw, db in outs:
         assert_close(db, ref_db, "bias gradient", tol=1e-5)
     assert_close(outs[1][0], outs[0][0], "weight gradient of the unaligned views")
+
+
+# n, h, w, cs, k, stride, padding: forward passes over 3-channel images; the one-pass kernel serves the 5 x 5 ones
+RGB_FWD_CASES = [
+    (64, 64, 64, 64, 5, 2, 'SAME'),        # DCGAN-64 / Text2Image d_h0 (benchmark size)
+    (3, 37, 29, 64, 5, 2, 'SAME'),         # ragged: 285 pixels, odd image sides, pad on every border
+    (2, 33, 33, 128, 5, 2, 'SAME'),        # two column tiles
+    (1, 40, 36, 64, 7, 1, 'REFLECT'),      # CycleGAN stem: 7 x 7 over the mirrored border (general kernel either way)
+    (2, 21, 23, 64, 7, 1, 'SAME'),         # 7 x 7 with zero padding
+    (2, 30, 30, 64, 5, 1, 'VALID'),
+    (1, 16, 16, 64, 5, 2, 'SAME'),         # fewer pixels than one workgroup
+]
+
+
+@pytest.mark.parametrize("case", RGB_FWD_CASES)
+@pytest.mark.parametrize("act", [None, 'lrelu'])
+def test_forward_over_rgb_images_without_slice_pipeline(L, case, act):
+    """The one-pass kernel for forward convolutions over 3-channel images (bias and fused activation on store) against
+    the float64 oracle, and against the general kernels it replaces (knob rgb_direct = 0): same arithmetic -- three
+    bf16 parts, six part products -- in another summation order."""
+    from gpu_util import assert_close, dev, geom_for, host
+    n, h, w, cs, k, s, padding = case
+    x = RNG.standard_normal((n, h, w, 3)).astype(np.float32)
+    wt = (RNG.standard_normal((k, k, 3, cs)) * 0.05).astype(np.float32)
+    b = RNG.standard_normal(cs).astype(np.float32)
+    g = geom_for(n, h, w, 3, cs, k, s, padding)
+    x64 = x.astype(np.float64)
+    if padding == 'REFLECT':
+        y_ref = T.conv2d_forward(T.reflect_pad(x64, (k - 1) // 2), wt.astype(np.float64), 1, 1, 'VALID') + b
+    else:
+        y_ref = T.conv2d_forward(x64, wt.astype(np.float64), s, s, padding) + b
+    if act == 'lrelu':
+        y_ref = T.lrelu(y_ref, 0.2)
+    x_d, w_d, b_d = dev(x), dev(wt), dev(b)
+    wp, wn = _ws(L, g)
+    outs = []
+    for direct in (1, 0):
+        L.knob_set("rgb_direct", direct)
+        y = torch.full(y_ref.shape, float('nan'), device='cuda')
+        gp = ctypes.byref(g)
+        if padding == 'REFLECT':
+            if act is not None:
+                continue
+            L.check(L.lib.gan_conv2d_fwd_reflect(gp, L.ptr(x_d), L.ptr(w_d), L.ptr(b_d), L.ptr(y), wp, wn, L.stream()))
+        elif act is None:
+            L.check(L.lib.gan_conv2d_fwd(gp, L.ptr(x_d), L.ptr(w_d), L.ptr(b_d), L.ptr(y), wp, wn, L.stream()))
+        else:
+            L.check(L.lib.gan_conv2d_fwd_act(gp, L.ptr(x_d), L.ptr(w_d), L.ptr(b_d), L.ptr(y), L.ACT_LRELU, 0.2, 1.0, 0.0, wp, wn,
+                                             L.stream()))
+        torch.cuda.synchronize()
+        assert_close(host(y), y_ref, "rgb forward %s (direct=%d)" % (case, direct))
+        outs.append(y)
+    if len(outs) == 2:
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[1].abs().max())
