@@ -228,9 +228,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 // ---------------------------------------------------------------------------- backward
 __device__ __forceinline__ float dz_of(float xv, float dyv, float mu, float rs, float ga, float be, int act,
                                        float act_param, float& xhat) {
+    // (no contraction left to the compiler: kernels that take these sums in different launch shapes must agree bit
+    // for bit, and a fused multiply-add formed at one call site and not at another differs in the last bit)
+#pragma clang fp contract(off)
     xhat = (xv - mu) * rs;
     if (act == GAN_ACT_NONE) return dyv;
-    const float z = xhat * ga + be;
+    const float z = fmaf(xhat, ga, be);
     return dyv * act_grad(z, apply_act(z, act, act_param), act, act_param);
 }
 
@@ -665,6 +668,16 @@ __device__ __forceinline__ void tile_bn_moments(const float2* __restrict__ parti
                       fmaxf(b.z - a.z * a.z * inv, 0.f) * inv, fmaxf(b.w - a.w * a.w * inv, 0.f) * inv);
 }
 
+// {mean, m2} of a row block from its shifted sums.  Contraction is switched off: the kernels that share this function
+// must produce the same bits, and a fused multiply-add the compiler forms at one call site and not at another differs
+// in the last bit whenever 1 / rows is inexact.
+__device__ __forceinline__ void tile_stats_finish(float4 shift, float4 s1, float4 s2, int rows, float4& mean, float4& m2) {
+#pragma clang fp contract(off)
+    const float inv = 1.0f / (float)rows;
+    mean = make_float4(shift.x + s1.x * inv, shift.y + s1.y * inv, shift.z + s1.z * inv, shift.w + s1.w * inv);
+    m2 = make_float4(s2.x - s1.x * s1.x * inv, s2.y - s1.y * s1.y * inv, s2.z - s1.z * s1.z * inv, s2.w - s1.w * s1.w * inv);
+}
+
 __device__ __forceinline__ void store_partial_quad(float2* partial, long idx, float4 a, float4 b) {
     float4* pp = reinterpret_cast<float4*>(partial + idx);
     pp[0] = make_float4(a.x, b.x, a.y, b.y);
@@ -699,10 +712,8 @@ __global__ __launch_bounds__(256) void bn_tile_stats_kernel(const float* __restr
             s1 = f4_add(s1, red[0][quad + 16 * j]);
             s2 = f4_add(s2, red[1][quad + 16 * j]);
         }
-        const float inv = 1.0f / (float)(r1 - r0);
-        const float4 mean = make_float4(shift.x + s1.x * inv, shift.y + s1.y * inv, shift.z + s1.z * inv, shift.w + s1.w * inv);
-        const float4 m2 = make_float4(s2.x - s1.x * s1.x * inv, s2.y - s1.y * s1.y * inv, s2.z - s1.z * s1.z * inv,
-                                      s2.w - s1.w * s1.w * inv);
+        float4 mean, m2;
+        tile_stats_finish(shift, s1, s2, r1 - r0, mean, m2);
         store_partial_quad(partial, ((long)grp * s.nb + rb) * s.c + ch0 + quad * 4, mean, m2);
     }
 }

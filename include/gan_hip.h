@@ -356,7 +356,8 @@ int gan_get_exact_f32(void);
  *   "rgb_gather"      GAN_HIP_RGB_GATHER=<0..2>  filter-row gather of the bf16 kernels for 3-channel images: 1 (default)
  *                                                forward and weight gradient, 2 weight gradient only, 0 off (those
  *                                                layers then run on the fp32 MFMA kernel)
- *   "no_bn_ride"      GAN_HIP_NO_BN_RIDE=<1|2>   1: gan_bn_tile_blocks reports 0, so callers keep the separate batch-norm
+ *   "no_bn_ride"      GAN_HIP_NO_BN_RIDE=<1|2>
+ *                                                1: gan_bn_tile_blocks reports 0, so callers keep the separate batch-norm
  *                                                launches; 2: the reductions of gan_conv_fwd_bn_stats / gan_conv_dgrad_bn_sums
  *                                                run as launches of their own behind the contraction (bit-identical)
  *   "rgb_direct"      GAN_HIP_RGB_DIRECT=0       forward passes over 3-channel images (5-row filters of up to 5 columns, output

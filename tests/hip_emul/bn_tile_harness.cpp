@@ -162,6 +162,9 @@ int main() {
     backward_case(3, 1300, 64, 2, GAN_ACT_RELU, 6);
     backward_case(2, 1296, 128, 1, GAN_ACT_NONE, 7);
     backward_case(2, 1296, 128, 4, GAN_ACT_TANH, 8);
+    // long row blocks (128 and 600 rows)
+    forward_case(1, 16384, 128, 2, 9);
+    backward_case(2, 19200, 256, 2, GAN_ACT_RELU, 13);
     printf("%s: %d failure(s)\n", g_failures ? "FAILED" : "ok", g_failures);
     return g_failures ? 1 : 0;
 }

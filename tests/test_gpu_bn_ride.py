@@ -42,6 +42,9 @@ FWD_CASES = [
     ("deconv2d", 6, 32, 128, 16, 3, 2, 3),   # 2048 rows per group x 128
     ("reflect", 2, 40, 32, 64, 3, 1, 1),     # 3200 rows
     ("reflect", 2, 36, 64, 128, 3, 1, 2),    # instance-norm style: one group per image, 1296 rows
+    ("conv2d", 64, 32, 16, 128, 5, 2, 1),    # 16384 rows: row blocks of 128 rows
+    ("conv2d", 50, 32, 8, 256, 3, 2, 2),     # 6400 rows per group, row blocks of 200 rows
+    ("deconv2d", 20, 32, 128, 16, 3, 2, 1),  # 20480 rows x 128, row blocks of 160
 ]
 
 
@@ -105,8 +108,9 @@ def test_forward_statistics_riding_on_the_slab_reduction_are_bit_identical(L, ca
     plain = run(False)
     L.knob_set("no_bn_ride", ride_knob)
     riding = run(True)
-    for a, b in zip(plain, riding):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+    for name, a, b in zip(("y", "z", "mean", "rstd", "moving_mean", "moving_var"), plain, riding):
+        assert torch.isfinite(a).all() and torch.equal(a, b), "%s differs: max |diff| %g at %d elements" % (
+            name, float((a - b).abs().max()), int((a != b).sum()))
 
 
 # op, n, big side, cb, cs, k, stride, groups of the batch norm whose output is the op's INPUT
@@ -118,6 +122,9 @@ BWD_CASES = [
     ("reflect", 2, 40, 64, 32, 3, 1, 1),      # fold of the mirrored border + sums, 3200 rows
     ("reflect", 2, 36, 128, 64, 3, 1, 2),
     ("reflect", 1, 40, 64, 8, 7, 1, 1),       # 7 x 7: three mirrored rows / columns onto one
+    ("conv2d", 32, 32, 128, 16, 5, 2, 1),     # 32768 rows: row blocks of 256 rows
+    ("deconv2d", 50, 32, 8, 256, 5, 2, 2),    # 6400 rows per group, row blocks of 200
+    ("conv2d", 40, 32, 64, 8, 3, 2, 1),       # 40960 rows x 64: row blocks of 160
 ]
 
 
