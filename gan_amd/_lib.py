@@ -84,6 +84,11 @@ SIGNATURES = {
     "gan_conv_dgrad_bn_sums": (I, [I, GeomP, P, P, P, ctypes.POINTER(BnSaved), P, P, Z, P]),
     "gan_bn_bwd_tiled": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, I, P, P]),
     "gan_conv_wgrad_colsum": (I, [I, GeomP, P, P, P, P, I, P, I, P, Z, P]),
+    "gan_taps_pack_filter": (I, [P, P, I, I, I, I, I, P]),
+    "gan_taps_unpack_filter_grad": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "gan_taps_sum_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
+    "gan_taps_sum_bwd": (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    "gan_taps_spread_bwd": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "gan_act_fwd": (I, [P, P, L, I, F, F, F, P]),
     "gan_act_bwd": (I, [P, P, P, L, I, F, F, F, P]),
     "gan_add_fwd": (I, [P, P, P, L, P]),

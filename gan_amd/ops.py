@@ -244,6 +244,85 @@ def _fwd_with_bn_stats(op, g, x, w, b, y, norm_tok, wp, wn):
     return True
 
 
+# Stride-1 convolutions with at most 4 channels on one side and a filter of 25 taps or more (the 7 x 7 image head and
+# stem of the CycleGAN generators) run as a dense product plus a sum over taps (include/gan_hip.h, gan_taps_*).
+TAPS_PATH = [True]
+
+
+def _taps_kind(g, reflect):
+    """'out': few OUTPUT channels (forward, weight and input gradient by taps); 'in': few INPUT channels (input gradient
+    by taps); None: the general kernels."""
+    if not TAPS_PATH[0] or g.sh != 1 or g.sw != 1 or g.kh != g.kw or not (g.kh & 1) or g.kh * g.kw < 25:
+        return None
+    if g.hs != g.hb or g.ws != g.wb or g.pt != (g.kh - 1) // 2 or g.pl != (g.kw - 1) // 2:
+        return None
+    if g.cs <= 4 and g.cb >= 16 and g.cb % 4 == 0:
+        return 'out'
+    if g.cb <= 4 and g.cs >= 16 and g.cs % 4 == 0:
+        return 'in'
+    return None
+
+
+def _taps_ld(g, thin):
+    return (g.kh * g.kw * thin + 3) & ~3
+
+
+def _taps_linear(kind, rows, i, o, a, b, out, extra=None):
+    """One of the three dense products of the tap decomposition, on the contraction kernels."""
+    if autotune.enabled():
+        autotune.tune_linear(rows, i, o)
+    wp, wn = _lin_ws(rows, i, o)
+    if kind == 'fwd':
+        check(lib.gan_linear_fwd(rows, i, o, ptr(a), ptr(b), None, ptr(out), wp, wn, stream()))
+    elif kind == 'dgrad':
+        check(lib.gan_linear_dgrad(rows, i, o, ptr(a), ptr(b), ptr(out), wp, wn, stream()))
+    else:
+        check(lib.gan_linear_wgrad(rows, i, o, ptr(a), ptr(b), ptr(out), ptr(extra), 0, wp, wn, stream()))
+
+
+def _taps_conv_fwd(g, x, w, b, y, reflect):
+    """Forward of a few-output-channel convolution; returns the repacked filter (the backward pass multiplies by it)."""
+    taps, ld, rows = g.kh * g.kw, _taps_ld(g, g.cs), g.n * g.hb * g.wb
+    wpk = torch.empty((g.cb, ld), dtype=torch.float32, device=x.device)
+    check(lib.gan_taps_pack_filter(ptr(w.data), ptr(wpk), taps, g.cb, g.cs, ld, 0, stream()))
+    z = torch.empty((rows, ld), dtype=torch.float32, device=x.device)
+    _taps_linear('fwd', rows, g.cb, ld, x, wpk, z)
+    check(lib.gan_taps_sum_fwd(ptr(z), ptr(b.data), ptr(y), g.n, g.hb, g.wb, g.cs, g.kh, g.kw, ld, int(reflect), stream()))
+    return wpk
+
+
+def _taps_conv_bwd(g, x, dy, w, b, wpk, reflect, want_dx):
+    """Weight, bias and input gradient of a few-output-channel convolution."""
+    taps, ld, rows = g.kh * g.kw, _taps_ld(g, g.cs), g.n * g.hb * g.wb
+    e = torch.empty((rows, ld), dtype=torch.float32, device=x.device)
+    check(lib.gan_taps_spread_bwd(ptr(dy), ptr(e), g.n, g.hb, g.wb, g.cs, g.kh, g.kw, ld, int(reflect), stream()))
+    if w.wants_grad:
+        dw, acc = w.grad_target()
+        db, accb = b.grad_target()
+        assert acc == accb
+        dwp = torch.empty((g.cb, ld), dtype=torch.float32, device=x.device)
+        dbp = torch.empty((ld,), dtype=torch.float32, device=x.device)
+        _taps_linear('wgrad', rows, g.cb, ld, x, e, dwp, dbp)
+        check(lib.gan_taps_unpack_filter_grad(ptr(dwp), ptr(dbp), ptr(dw), ptr(db), taps, g.cb, g.cs, ld, 0, acc, stream()))
+    if not want_dx:
+        return None
+    dx = torch.empty_like(x)
+    _taps_linear('dgrad', rows, g.cb, ld, e, wpk, dx)
+    return dx
+
+
+def _taps_stem_dgrad(g, dy, w, x, reflect):
+    """Input gradient of a few-INPUT-channel convolution (filter [t][o][c])."""
+    taps, ld, rows = g.kh * g.kw, _taps_ld(g, g.cb), g.n * g.hb * g.wb
+    wpk = torch.empty((g.cs, ld), dtype=torch.float32, device=dy.device)
+    check(lib.gan_taps_pack_filter(ptr(w.data), ptr(wpk), taps, g.cs, g.cb, ld, 1, stream()))
+    z = torch.empty((rows, ld), dtype=torch.float32, device=dy.device)
+    _taps_linear('fwd', rows, g.cs, ld, dy, wpk, z)
+    dx = torch.empty_like(x)
+    check(lib.gan_taps_sum_bwd(ptr(z), ptr(dx), g.n, g.hb, g.wb, g.cb, g.kh, g.kw, ld, int(reflect), stream()))
+    return dx
+
+
 def _act_spec(act, act_param, act_scale, act_shift):
     code = ACT_CODES[act]
     if code == _lib.ACT_NONE and act_scale == 1.0 and act_shift == 0.0:
@@ -283,7 +362,10 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.norm_tok, ctx.in_bn = norm_tok, in_bn
         if reflect and (act_tok is not None or in_tok is not None):
             raise ValueError("conv2d: REFLECT padding does not combine with a fused activation")
-        if norm_tok is not None and act_tok is None and _fwd_with_bn_stats(ctx.op, g, x, w, b, y, norm_tok, wp, wn):
+        ctx.taps = _taps_kind(g, reflect) if (act_tok is None and in_tok is None) else None
+        if ctx.taps == 'out':
+            ctx.save_for_backward(x, _taps_conv_fwd(g, x, w, b, y, reflect))
+        elif norm_tok is not None and act_tok is None and _fwd_with_bn_stats(ctx.op, g, x, w, b, y, norm_tok, wp, wn):
             ctx.save_for_backward(x)
         elif reflect:
             check(lib.gan_conv2d_fwd_reflect(ctypes.byref(g), ptr(x), ptr(w.data), ptr(b.data), ptr(y), wp, wn, stream()))
@@ -306,12 +388,16 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.act_tok is not None:
             dy = _through_own_activation(ctx, ctx.saved_tensors[1], dy)
         dy = _dense(dy)
+        if ctx.taps == 'out':
+            return (_taps_conv_bwd(g, x, dy, w, b, ctx.saved_tensors[1], ctx.reflect, ctx.needs_input_grad[0]),) + (None,) * 9
         wp, wn = _conv_ws(g)
         if w.wants_grad:
             _wgrad(ctx.op, lib.gan_conv2d_wgrad_reflect if ctx.reflect else lib.gan_conv2d_wgrad, g, x, dy, w, b, ctx.norm_tok,
                    wp, wn)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.taps == 'in':
+            dx = _taps_stem_dgrad(g, dy, w, x, ctx.reflect)
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if ctx.in_bn is not None and ctx.in_tok is None and ctx.reflect and g.pt == g.pl and \
                     _dgrad_with_bn_sums(ctx.op, g, dy, w, dx, ctx.in_bn, *_reflect_dgrad_ws(g)):

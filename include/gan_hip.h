@@ -241,6 +241,32 @@ int gan_conv_wgrad_colsum(int op, const gan_conv_geom* g, const float* x, const 
                           int accumulate, const float* colsum_partial, int colsum_blocks, void* ws,
                           size_t ws_bytes, gan_stream_t stream);
 
+/* ---- stride-1 convolutions with few channels on one side, as a dense product plus a sum over taps ----------------
+ * No counterpart in the reference (it calls tf.nn.conv2d for these layers like for any other): the 7 x 7, 64 -> 3
+ * image head of the CycleGAN generators (cyclegan_module.py:143-144) fills 3 of the 32 columns of a matrix-pipe tile and
+ * gathers every input value 49 times.  With T = kh * kw taps and rows of ld = T * cs rounded up to a multiple of 4:
+ *   forward   Z[p, (t,o)] = sum_c x[p,c] w[t,c,o]  (gan_linear_fwd with the filter repacked by gan_taps_pack_filter to
+ *             [cb][ld]), then gan_taps_sum_fwd: y[p,o] = bias[o] + sum_t Z[R(p+t), (t,o)], R = mirror (reflect != 0) or
+ *             drop (zero padding); the padding is (k-1)/2 on every side, the stride 1.
+ *   backward  gan_taps_spread_bwd: E[q, (t,o)] = sum over the pixels p whose tap t lands on q of dy[p,o]; then
+ *             gan_linear_wgrad(x, E) gives the repacked filter gradient (and column sums whose centre-tap entries are the
+ *             bias gradient), gan_taps_unpack_filter_grad puts both where they belong (accumulate as elsewhere), and
+ *             gan_linear_dgrad(E, repacked filter) is the input gradient.
+ *   thin INPUT side (the 3 -> 64 stem, cyclegan_module.py:124-125): its input gradient is
+ *             Z = gan_linear_fwd(dy, filter repacked with transposed != 0: the filter is [t][o][c] there), then
+ *             gan_taps_sum_bwd: dx[q,o] = sum_t sum over the pixels p whose tap t lands on q of Z[p, (t,o)].
+ * cs <= 4, odd kh / kw.  Same values as the gan_conv2d_*_reflect / gan_conv2d_* entry points up to fp32 summation order. */
+int gan_taps_pack_filter(const float* w, float* wp, int taps, int cb, int cs, int ld, int transposed,
+                         gan_stream_t stream);
+int gan_taps_unpack_filter_grad(const float* dwp, const float* dbp, float* dw, float* db, int taps, int cb, int cs,
+                                int ld, int transposed, int accumulate, gan_stream_t stream);
+int gan_taps_sum_fwd(const float* z, const float* bias, float* y, int n, int h, int w, int cs, int kh, int kw,
+                     int ld, int reflect, gan_stream_t stream);
+int gan_taps_sum_bwd(const float* z, float* dx, int n, int h, int w, int cs, int kh, int kw, int ld, int reflect,
+                     gan_stream_t stream);
+int gan_taps_spread_bwd(const float* dy, float* e, int n, int h, int w, int cs, int kh, int kw, int ld, int reflect,
+                        gan_stream_t stream);
+
 /* ---- stand-alone activations (ops.py:101-102; dcgan.py:334,368-385,409; text2image.py:198)
  * forward: y = act(x)*scale + shift; backward from the saved y: dx = dy*scale*act'(.) */
 int gan_act_fwd(const float* x, float* y, long n, int act, float act_param, float scale, float shift,

@@ -244,3 +244,58 @@ def test_fused_activation_output_with_two_consumers_is_refused(gated_first):
         with pytest.raises(RuntimeError, match="feeds a gated consumer AND something else"):
             ops.backward(losses)
         torch.cuda.synchronize()
+
+
+# n, h, w, cin, cout, k, padding: stride-1 convolutions with few channels on one side
+TAPS_CASES = [
+    (1, 40, 36, 64, 3, 7, 'REFLECT'),     # the CycleGAN image head: forward, filter / bias / input gradient by taps
+    (2, 9, 11, 16, 3, 7, 'REFLECT'),      # an image barely larger than the padding
+    (2, 20, 24, 32, 2, 5, 'SAME'),        # zero padding
+    (1, 40, 36, 3, 64, 7, 'REFLECT'),     # the CycleGAN stem: input gradient by taps
+    (2, 18, 16, 1, 32, 5, 'SAME'),
+]
+
+
+@pytest.mark.parametrize("case", TAPS_CASES)
+def test_few_channel_convolutions_by_taps(case):
+    """ops.conv2d on layers with at most 4 channels on one side and 25 taps or more, computed as a dense product plus a
+    sum over taps (gan_taps_*), against the same call on the general kernels (ops.TAPS_PATH off): loss, every
+    variable's gradient (two uses of the layer, so the second accumulates) and the input gradient."""
+    from gan_amd import ops, variables as V
+    from gan_amd.optim import AdamOptimizer
+    n, h, w_, cin, cout, k, padding = case
+    torch.manual_seed(9)
+    x_d = torch.randn(n, h, w_, cin, device='cuda')
+    bias_d = torch.rand(cout, device='cuda') * 2 - 1
+    res = []
+    try:
+        for taps in (True, False):
+            ops.TAPS_PATH[0] = taps
+            store = V.VariableStore(device='cuda', seed=3)
+            with V.use_store(store):
+                def net(inp):
+                    with ops.variable_scope("l") as scope:
+                        a = ops.conv2d(inp, cout, k, k, 1, 1, padding=padding, name='c')
+                        scope.reuse_variables()
+                        b = ops.conv2d(inp * 0.5, cout, k, k, 1, 1, padding=padding, name='c')
+                    return [ops.mse_const_mean(a, 0.1), ops.mse_const_mean(b, -0.2)]
+                net(x_d)
+                store.vars['l/c/biases'].data.copy_(bias_d)
+                group = store.pack('n', store.trainable_variables())
+                opt = AdamOptimizer(1e-3, beta1=0.5).attach(group)
+                opt.begin()
+                xin = x_d.clone().requires_grad_(True)
+                losses = net(xin)
+                ops.backward(losses)
+                opt.finish_grads()
+                torch.cuda.synchronize()
+                res.append(([float(v.detach()) for v in losses], {v.name: v.grad.clone() for v in group.variables}, xin.grad.clone()))
+    finally:
+        ops.TAPS_PATH[0] = True
+    (l0, g0, dx0), (l1, g1, dx1) = res
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+    for name in g1:
+        assert torch.isfinite(g0[name]).all()
+        assert float((g0[name] - g1[name]).abs().max()) <= 2e-5 * float(g1[name].abs().max()), name
+    assert float((dx0 - dx1).abs().max()) <= 2e-5 * float(dx1.abs().max())
