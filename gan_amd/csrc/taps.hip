@@ -72,22 +72,48 @@ __global__ void taps_unpack_grad_kernel(const float* __restrict__ dwp, const flo
         db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + dbp[centre * cs + threadIdx.x];
 }
 
-// y[p, o] = bias[o] + sum_t Z[R(p + t), (t, o)]; one work-item per pixel, CS channels in registers.
+// The two tap sums read T * CS values per pixel from T different rows of Z: one work-item per pixel is a chain of T
+// dependent-latency loads on 1/8 of the chip's wave slots.  A workgroup therefore takes 32 pixels x 8 filter-row
+// slots (work-item = (slot, pixel); slot s adds the filter rows s, s + 8, ...), and the slot sums meet in LDS in
+// slot order: deterministic, 8 times the loads in flight.
+constexpr int kTapPixels = 32, kTapSlots = 8;
+
 template <int CS>
-__global__ __launch_bounds__(256) void taps_sum_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias,
-                                                           float* __restrict__ y, const TapGeom g) {
+__device__ __forceinline__ void tap_slots_finish(float (&acc)[CS], const float* __restrict__ bias, float* __restrict__ out, long p,
+                                                 bool pvalid) {
+    __shared__ float red[kTapSlots][kTapPixels][CS];
+    const int pl = threadIdx.x % kTapPixels, slot = threadIdx.x / kTapPixels;
+#pragma unroll
+    for (int o = 0; o < CS; ++o) red[slot][pl][o] = acc[o];
+    __syncthreads();
+    if (slot == 0 && pvalid) {
+#pragma unroll
+        for (int o = 0; o < CS; ++o) {
+            float v = bias != nullptr ? bias[o] : 0.f;
+            for (int sl = 0; sl < kTapSlots; ++sl) v += red[sl][pl][o];
+            out[p * CS + o] = v;
+        }
+    }
+}
+
+// y[p, o] = bias[o] + sum_t Z[R(p + t), (t, o)]
+template <int CS>
+__global__ __launch_bounds__(kTapPixels * kTapSlots) void taps_sum_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                                            float* __restrict__ y, const TapGeom g) {
     const long pixels = (long)g.n * g.h * g.w;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= pixels) return;
-    const int px = (int)(p % g.w);
-    const long r = p / g.w;
+    const int pl = threadIdx.x % kTapPixels, slot = threadIdx.x / kTapPixels;
+    const long p = (long)blockIdx.x * kTapPixels + pl;
+    const bool pvalid = p < pixels;
+    const long pc = pvalid ? p : 0;
+    const int px = (int)(pc % g.w);
+    const long r = pc / g.w;
     const int py = (int)(r % g.h);
     const long img = r / g.h;
     const int pady = (g.kh - 1) / 2, padx = (g.kw - 1) / 2;
     float acc[CS];
 #pragma unroll
-    for (int o = 0; o < CS; ++o) acc[o] = bias != nullptr ? bias[o] : 0.f;
-    for (int ty = 0; ty < g.kh; ++ty) {
+    for (int o = 0; o < CS; ++o) acc[o] = 0.f;
+    for (int ty = slot; ty < g.kh && pvalid; ty += kTapSlots) {
         int sy = py + ty - pady;
         if (g.reflect) sy = tap_reflect(sy, g.h);
         if (sy < 0 || sy >= g.h) continue;
@@ -100,25 +126,27 @@ __global__ __launch_bounds__(256) void taps_sum_fwd_kernel(const float* __restri
             for (int o = 0; o < CS; ++o) acc[o] += src[o];
         }
     }
-#pragma unroll
-    for (int o = 0; o < CS; ++o) y[p * CS + o] = acc[o];
+    tap_slots_finish<CS>(acc, bias, y, p, pvalid);
 }
 
 // dx[q, o] = sum_t sum_{p in Pre(q, t)} Z[p, (t, o)]
 template <int CS>
-__global__ __launch_bounds__(256) void taps_sum_bwd_kernel(const float* __restrict__ z, float* __restrict__ dx, const TapGeom g) {
+__global__ __launch_bounds__(kTapPixels * kTapSlots) void taps_sum_bwd_kernel(const float* __restrict__ z, float* __restrict__ dx,
+                                                                            const TapGeom g) {
     const long pixels = (long)g.n * g.h * g.w;
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= pixels) return;
-    const int qx = (int)(q % g.w);
-    const long r = q / g.w;
+    const int pl = threadIdx.x % kTapPixels, slot = threadIdx.x / kTapPixels;
+    const long q = (long)blockIdx.x * kTapPixels + pl;
+    const bool qvalid = q < pixels;
+    const long qc = qvalid ? q : 0;
+    const int qx = (int)(qc % g.w);
+    const long r = qc / g.w;
     const int qy = (int)(r % g.h);
     const long img = r / g.h;
     const int pady = (g.kh - 1) / 2, padx = (g.kw - 1) / 2;
     float acc[CS];
 #pragma unroll
     for (int o = 0; o < CS; ++o) acc[o] = 0.f;
-    for (int ty = 0; ty < g.kh; ++ty) {
+    for (int ty = slot; ty < g.kh && qvalid; ty += kTapSlots) {
         int ys[3];
         const int ny = tap_preimages(qy, ty, pady, g.h, g.reflect, ys);
         for (int tx = 0; tx < g.kw; ++tx) {
@@ -132,41 +160,38 @@ __global__ __launch_bounds__(256) void taps_sum_bwd_kernel(const float* __restri
                 }
         }
     }
-#pragma unroll
-    for (int o = 0; o < CS; ++o) dx[q * CS + o] = acc[o];
+    tap_slots_finish<CS>(acc, nullptr, dx, q, qvalid);
 }
 
-// E[q, j] for four consecutive columns j = (t, o) per work-item: sum over Pre(q, t) of dy[p, o]; pad columns zero.
+// E[q, (t, o)] = sum over Pre(q, t) of dy[p, o]: one work-item per (pixel, tap slot); the slot behind the last tap
+// writes the zero pad columns of the row.
 __global__ __launch_bounds__(256) void taps_spread_bwd_kernel(const float* __restrict__ dy, float* __restrict__ e, const TapGeom g) {
-    const int ld4 = g.ld >> 2;
-    const long total = (long)g.n * g.h * g.w * ld4;
+    const int taps = g.kh * g.kw;
+    const int slots = taps + (g.ld > taps * g.cs ? 1 : 0);
+    const long total = (long)g.n * g.h * g.w * slots;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int j4 = (int)(i % ld4);
-    const long q = i / ld4;
+    const int t = (int)(i % slots);
+    const long q = i / slots;
+    float* row = e + q * g.ld;
+    if (t == taps) {
+        for (int j = taps * g.cs; j < g.ld; ++j) row[j] = 0.f;
+        return;
+    }
     const int qx = (int)(q % g.w);
     const long r = q / g.w;
     const int qy = (int)(r % g.h);
     const long img = r / g.h;
-    const int pady = (g.kh - 1) / 2, padx = (g.kw - 1) / 2;
-    const int taps = g.kh * g.kw;
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = j4 * 4 + k;
-        const int t = j / g.cs, o = j - t * g.cs;
+    const int ty = t / g.kw, tx = t - ty * g.kw;
+    int ys[3], xs[3];
+    const int ny = tap_preimages(qy, ty, (g.kh - 1) / 2, g.h, g.reflect, ys);
+    const int nx = tap_preimages(qx, tx, (g.kw - 1) / 2, g.w, g.reflect, xs);
+    for (int o = 0; o < g.cs; ++o) {
         float s = 0.f;
-        if (t < taps) {
-            const int ty = t / g.kw, tx = t - ty * g.kw;
-            int ys[3], xs[3];
-            const int ny = tap_preimages(qy, ty, pady, g.h, g.reflect, ys);
-            const int nx = tap_preimages(qx, tx, padx, g.w, g.reflect, xs);
-            for (int a = 0; a < ny; ++a)
-                for (int b = 0; b < nx; ++b) s += dy[((img * g.h + ys[a]) * g.w + xs[b]) * g.cs + o];
-        }
-        v[k] = s;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) s += dy[((img * g.h + ys[a]) * g.w + xs[b]) * g.cs + o];
+        row[t * g.cs + o] = s;
     }
-    reinterpret_cast<float4*>(e)[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 static int tap_geom_check(const char* what, const TapGeom& g) {
@@ -176,7 +201,8 @@ static int tap_geom_check(const char* what, const TapGeom& g) {
     GAN_CHECK_ARG(g.ld >= g.kh * g.kw * g.cs && (g.ld & 3) == 0, "%s: rows of %d floats cannot hold %d x %d x %d columns in multiples of 4",
                   what, g.ld, g.kh, g.kw, g.cs);
     GAN_CHECK_ARG(!g.reflect || ((g.kh - 1) / 2 < g.h && (g.kw - 1) / 2 < g.w), "%s: REFLECT padding must be smaller than the image", what);
-    GAN_CHECK_ARG((long)g.n * g.h * g.w * g.ld < (1L << 40), "%s: tensor too large", what);
+    GAN_CHECK_ARG((long)g.n * g.h * g.w * g.ld < (1L << 40) && ((long)g.n * g.h * g.w * (g.kh * g.kw + 1) + 255) / 256 < (1L << 31),
+                  "%s: tensor too large", what);
     return 0;
 }
 
@@ -219,8 +245,8 @@ extern "C" int gan_taps_sum_fwd(const float* z, const float* bias, float* y, int
     const TapGeom g = TapGeom{n, h, w, cs, kh, kw, ld, reflect ? 1 : 0};
     if (int rc = tap_geom_check("gan_taps_sum_fwd", g)) return rc;
     GAN_CHECK_ARG(z && y, "gan_taps_sum_fwd: NULL tensor");
-    const dim3 grid(blocks_for((long)n * h * w));
-    GAN_TAPS_CS_DISPATCH(taps_sum_fwd_kernel, cs, grid, dim3(256), 0, as_stream(stream), z, bias, y, g);
+    const dim3 grid((unsigned)(((long)n * h * w + kTapPixels - 1) / kTapPixels));
+    GAN_TAPS_CS_DISPATCH(taps_sum_fwd_kernel, cs, grid, dim3(kTapPixels * kTapSlots), 0, as_stream(stream), z, bias, y, g);
     return check_launch("gan_taps_sum_fwd");
 }
 
@@ -229,8 +255,8 @@ extern "C" int gan_taps_sum_bwd(const float* z, float* dx, int n, int h, int w, 
     const TapGeom g = TapGeom{n, h, w, cs, kh, kw, ld, reflect ? 1 : 0};
     if (int rc = tap_geom_check("gan_taps_sum_bwd", g)) return rc;
     GAN_CHECK_ARG(z && dx, "gan_taps_sum_bwd: NULL tensor");
-    const dim3 grid(blocks_for((long)n * h * w));
-    GAN_TAPS_CS_DISPATCH(taps_sum_bwd_kernel, cs, grid, dim3(256), 0, as_stream(stream), z, dx, g);
+    const dim3 grid((unsigned)(((long)n * h * w + kTapPixels - 1) / kTapPixels));
+    GAN_TAPS_CS_DISPATCH(taps_sum_bwd_kernel, cs, grid, dim3(kTapPixels * kTapSlots), 0, as_stream(stream), z, dx, g);
     return check_launch("gan_taps_sum_bwd");
 }
 
@@ -239,8 +265,8 @@ extern "C" int gan_taps_spread_bwd(const float* dy, float* e, int n, int h, int 
     const TapGeom g = TapGeom{n, h, w, cs, kh, kw, ld, reflect ? 1 : 0};
     if (int rc = tap_geom_check("gan_taps_spread_bwd", g)) return rc;
     GAN_CHECK_ARG(dy && e, "gan_taps_spread_bwd: NULL tensor");
-    GAN_CHECK_ARG((reinterpret_cast<size_t>(e) & 15) == 0, "gan_taps_spread_bwd: e must be 16-byte aligned");
-    const dim3 grid(blocks_for((long)n * h * w * (ld / 4)));
+    const int slots = kh * kw + (ld > kh * kw * cs ? 1 : 0);
+    const dim3 grid(blocks_for((long)n * h * w * slots));
     hipLaunchKernelGGL(taps_spread_bwd_kernel, grid, dim3(256), 0, as_stream(stream), dy, e, g);
     return check_launch("gan_taps_spread_bwd");
 }
