@@ -47,6 +47,25 @@ class ContractionTimer(object):
             "gan_conv2d_fwd_act", "gan_deconv2d_fwd_act", "gan_conv2d_dgrad_gated", "gan_deconv2d_dgrad_gated",
             "gan_conv2d_fwd_reflect", "gan_conv2d_wgrad_reflect", "gan_conv2d_dgrad_reflect"]
     LIN = ["gan_linear_fwd", "gan_linear_dgrad", "gan_linear_wgrad"]
+    # entry points that run a contraction and let a batch-norm reduction ride on it: (op, geometry, ...); counted under
+    # the name of the plain entry point of the same contraction
+    RIDE = {"gan_conv_fwd_bn_stats": ("gan_conv2d_fwd", "gan_deconv2d_fwd", "gan_conv2d_fwd_reflect"),
+            "gan_conv_dgrad_bn_sums": ("gan_conv2d_dgrad", "gan_deconv2d_dgrad", "gan_conv2d_dgrad_reflect"),
+            "gan_conv_wgrad_colsum": ("gan_conv2d_wgrad", "gan_deconv2d_wgrad", "gan_conv2d_wgrad_reflect")}
+
+    @classmethod
+    def describe(cls, name, args):
+        """(name of the plain entry point, shape tuple, nominal FLOP, algorithmic bytes) of one call."""
+        if name in cls.LIN:
+            rows, i, o = (int(v) for v in args[:3])
+            return name, (rows, i, o), 2.0 * rows * i * o, 4.0 * (rows * i + rows * o + i * o)
+        if name in cls.RIDE:
+            name, g = cls.RIDE[name][int(args[0])], args[1]._obj
+        else:
+            g = args[0]._obj
+        shape = (g.n, g.hb, g.wb, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl)
+        nbytes = 4.0 * (g.n * g.hb * g.wb * g.cb + g.n * g.hs * g.ws * g.cs + g.kh * g.kw * g.cb * g.cs)
+        return name, shape, conv_flops(g), nbytes
 
     def __init__(self, L):
         self.L = L
@@ -55,7 +74,7 @@ class ContractionTimer(object):
 
     def __enter__(self):
         lib = self.L.lib
-        for name in self.CONV + self.LIN:
+        for name in self.CONV + self.LIN + list(self.RIDE):
             fn = getattr(lib, name)
             self.saved[name] = fn
             setattr(lib, name, self._wrap(name, fn))
@@ -66,21 +85,13 @@ class ContractionTimer(object):
             setattr(self.L.lib, name, fn)
 
     def _wrap(self, name, fn):
-        is_conv = name in self.CONV
-
         def call(*args):
-            if is_conv:
-                g = args[0]._obj
-                flops = conv_flops(g)
-                shape = (g.n, g.hb, g.wb, g.cb, g.hs, g.ws, g.cs, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl)
-            else:
-                flops = 2.0 * args[0] * args[1] * args[2]
-                shape = tuple(args[:3])
+            plain, shape, flops, _ = self.describe(name, args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*args)
             e1.record()
-            self.records.append((name, shape, flops, e0, e1))
+            self.records.append((plain, shape, flops, e0, e1))
             return rc
         return call
 
@@ -105,18 +116,17 @@ class ContractionRecorder(ContractionTimer):
     it through, so that the same launches can be issued again on the same buffers."""
 
     def _wrap(self, name, fn):
-        is_conv = name in self.CONV
-
         def call(*args):
-            if is_conv:
-                g = args[0]._obj
-                flops = conv_flops(g)
-                nbytes = 4.0 * (g.n * g.hb * g.wb * g.cb + g.n * g.hs * g.ws * g.cs + g.kh * g.kw * g.cb * g.cs)
-            else:
-                rows, i, o = args[:3]
-                flops = 2.0 * rows * i * o
-                nbytes = 4.0 * (rows * i + rows * o + i * o)
-            self.records.append((fn, args, flops, nbytes))
+            plain, shape, flops, nbytes = self.describe(name, args)
+            # What is issued again, alone, is the CONTRACTION: a forward / input-gradient call that lets a batch-norm
+            # reduction ride on its slab reduction is re-issued as the plain entry point of the same contraction (same
+            # kernels, plan and slabs); the weight gradient that takes its bias gradient from given column sums as it is.
+            again_fn, again_args = fn, args
+            if name == "gan_conv_fwd_bn_stats":
+                again_fn, again_args = self.saved[plain], args[1:6] + args[8:]
+            elif name == "gan_conv_dgrad_bn_sums":
+                again_fn, again_args = self.saved[plain], args[1:5] + args[7:]
+            self.records.append((again_fn, again_args, flops, nbytes, plain, shape))
             return fn(*args)
         return call
 
@@ -134,7 +144,7 @@ def contraction_sequence_time(model, batch, L, replays=20):
             model.train_iteration(*batch)
     only = torch.cuda.CUDAGraph()
     with torch.cuda.graph(only):
-        for fn, args, _, _ in rec.records:
+        for fn, args, *_ in rec.records:
             rc = fn(*(tuple(args[:-1]) + (stream(),)))         # the stream is every entry point's last argument
             if rc != 0:
                 raise SystemExit("re-issuing a recorded contraction call failed: %s" % L.lib.gan_last_error().decode())

@@ -82,7 +82,7 @@ def main():
             model.train_iteration(im, z)
     only = torch.cuda.CUDAGraph()
     with torch.cuda.graph(only):
-        for fn, a, _, _ in rec.records:
+        for fn, a, *_ in rec.records:
             _lib.check(fn(*(tuple(a[:-1]) + (stream(),))))
     only.replay()
     torch.cuda.synchronize()
@@ -94,13 +94,7 @@ def main():
     flops = sum(r[2] for r in rec.records)
     # which plans and which library sources these launches belong to (bench.py attaches the traffic figure only to runs
     # with the same two hashes)
-    calls = []
-    for fn, a, _, _ in rec.records:
-        name = fn.__name__ if hasattr(fn, "__name__") else str(fn)
-        if name.startswith("gan_linear"):
-            calls.append((name, tuple(int(v) for v in a[:3])))
-        else:
-            calls.append((name, tuple(a[0]._obj.key())))
+    calls = [(plain, shape) for _, _, _, _, plain, shape in rec.records]
     meta = {"plans_sha16": bench.plan_set_sha16(_lib, sorted(set(calls))), "source_sha16": bench.source_sha16(),
             "plans_file": args.plans and os.path.relpath(os.path.abspath(args.plans), bench.ROOT), "replays": args.replays}
     if args.meta:
