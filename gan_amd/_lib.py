@@ -82,6 +82,7 @@ SIGNATURES = {
     "gan_conv_fwd_bn_stats": (I, [I, GeomP, P, P, P, P, I, P, P, Z, P]),
     "gan_bn_fwd_train_from_stats": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, I, F, P, P]),
     "gan_conv_dgrad_bn_sums": (I, [I, GeomP, P, P, P, ctypes.POINTER(BnSaved), P, P, Z, P]),
+    "gan_add_bn_sums": (I, [P, P, P, ctypes.POINTER(BnSaved), I, I, P, P]),
     "gan_bn_bwd_tiled": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, I, P, P]),
     "gan_conv_wgrad_colsum": (I, [I, GeomP, P, P, P, P, I, P, I, P, Z, P]),
     "gan_taps_pack_filter": (I, [P, P, I, I, I, I, I, P]),

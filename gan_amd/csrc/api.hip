@@ -376,6 +376,27 @@ extern "C" int gan_conv_dgrad_bn_sums(int op, const gan_conv_geom* g, const floa
     return rc;
 }
 
+// out = a + b with the block sums of a batch norm's backward over `out`: the two addends are read as two "slabs" whose
+// distance is the distance of the two tensors (the slab-summing variant of the sums kernel adds slab 0 + slab 1, which
+// is the add kernel's a + b), every sum is stored to `out` and taken into the reduction.
+extern "C" int gan_add_bn_sums(const float* a, const float* b, float* out, const gan_bn_saved* bn, int rows, int c,
+                               float* bn_partial, gan_stream_t stream) {
+    const char* what = "gan_add_bn_sums";
+    GAN_CHECK_ARG(a && b && out && bn != nullptr && bn_partial != nullptr && bn->x && bn->gamma && bn->beta && bn->save_mean &&
+                  bn->save_rstd, "%s: NULL tensor", what);
+    GAN_CHECK_ARG(bn->act >= GAN_ACT_NONE && bn->act <= GAN_ACT_SIGMOID, "%s: unknown activation %d", what, bn->act);
+    GAN_CHECK_ARG(bn->groups > 0 && rows > 0 && c > 0, "%s: groups, rows and c must be positive", what);
+    TileBn ts;
+    GAN_CHECK_ARG(bn_ride_plan(bn->groups, rows, c, true, &ts),
+                  "%s: no block decomposition exists for %d x %d x %d (gan_bn_tile_blocks reports 0)", what, bn->groups, rows, c);
+    GAN_CHECK_ARG((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
+                  "%s: the addends must be 16-byte aligned", what);
+    const BnRide ride = BnRide{2, reinterpret_cast<float2*>(bn_partial), ts, bn->x, bn->gamma, bn->beta, bn->save_mean,
+                               bn->save_rstd, bn->act, bn->act_param};
+    const long apart = (long)((reinterpret_cast<intptr_t>(b) - reinterpret_cast<intptr_t>(a)) / (intptr_t)sizeof(float));
+    return launch_bn_ride(ride, RowSource{a, out, nullptr, apart, 2}, as_stream(stream), what);
+}
+
 extern "C" int gan_conv_wgrad_colsum(int op, const gan_conv_geom* g, const float* x, const float* dy, float* dw, float* db,
                                      int accumulate, const float* colsum_partial, int colsum_blocks, void* ws,
                                      size_t ws_bytes, gan_stream_t stream) {

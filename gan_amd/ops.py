@@ -133,7 +133,7 @@ def _bn_ws(groups, rows, c):
 
 # which batch-norm reductions ride on neighbouring contraction launches (all by default; tests and measurements switch
 # them one by one): forward statistics, backward sums, column sums for the bias gradient of the layer in front
-RIDE_PARTS = {'stats': True, 'sums': True, 'colsum': True}
+RIDE_PARTS = {'stats': True, 'sums': True, 'colsum': True, 'fan_out': True}
 
 
 def _tile_blocks(groups, rows, c, backward):
@@ -209,6 +209,20 @@ def _dgrad_with_bn_sums(op, g, dy, w, dx, in_bn, wp, wn):
     check(lib.gan_conv_dgrad_bn_sums(op, ctypes.byref(g), ptr(dy), ptr(w.data), ptr(dx), ctypes.byref(saved), ptr(partial),
                                      wp, wn, stream()))
     in_bn.sums = (dx, dx._version, partial)
+    return True
+
+
+def _add_with_bn_sums(a, b, out, in_bn):
+    """out = a + b, the gradient of a batch norm's output that had two consumers, leaving that norm's backward block
+    sums with the token; False when the norm's shape has no such decomposition."""
+    bx, mean, rstd, gamma, beta, groups, rows, c, act, act_param = in_bn.saved
+    nb = _tile_blocks(groups, rows, c, 1) if RIDE_PARTS['fan_out'] else 0
+    if not nb or out.numel() != groups * rows * c or (a.data_ptr() | b.data_ptr() | out.data_ptr()) & 15:
+        return False
+    partial = torch.empty(2 * groups * nb * c, dtype=torch.float32, device=out.device)
+    saved = _lib.BnSaved(ptr(bx), ptr(gamma.data), ptr(beta.data), ptr(mean), ptr(rstd), groups, act, act_param)
+    check(lib.gan_add_bn_sums(ptr(a), ptr(b), ptr(out), ctypes.byref(saved), rows, c, ptr(partial), stream()))
+    in_bn.sums = (out, out._version, partial)
     return True
 
 
@@ -847,20 +861,24 @@ class _ForkFn(torch.autograd.Function):
     add kernel (left to itself, autograd would accumulate them with a torch operator)."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, in_bn=None):
+        ctx.in_bn = in_bn
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
         grads = [_dense(g) for g in grads if g is not None]
         if not grads:
-            return None, None
+            return None, None, None
         total = grads[0]
-        for g in grads[1:]:
+        for i, g in enumerate(grads[1:]):
             out = torch.empty_like(total)
-            check(lib.gan_add_fwd(ptr(total), ptr(g), ptr(out), total.numel(), stream()))
+            # x came out of a batch norm: the launch that finishes its gradient also takes that norm's backward sums
+            if not (i == len(grads) - 2 and ctx.in_bn is not None and ctx.in_bn.saved is not None and
+                    _add_with_bn_sums(total, g, out, ctx.in_bn)):
+                check(lib.gan_add_fwd(ptr(total), ptr(g), ptr(out), total.numel(), stream()))
             total = out
-        return total, None
+        return total, None, None
 
 
 def fork(x, n=2):
@@ -868,7 +886,7 @@ def fork(x, n=2):
     discriminator and the other generator).  Without a backward pass to run it returns `x` n times."""
     if not (torch.is_grad_enabled() and x.requires_grad):
         return (x,) * n
-    return _ForkFn.apply(x, n)
+    return _ForkFn.apply(x, n, _bn_of(x))
 
 
 class _ConcatFn(torch.autograd.Function):

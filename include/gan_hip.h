@@ -204,6 +204,10 @@ int gan_bn_bwd(const float* x, const float* gamma, const float* beta, const floa
  *   bias      gan_bn_bwd_tiled with colsum_partial != NULL also leaves the column sums of the rows of dx each of its
  *             workgroups stored; gan_conv_wgrad_colsum = the weight gradient of the layer in front of the batch norm,
  *             taking its bias gradient db from those instead of reading dx again in a launch of its own.
+ *   fan-out   gan_add_bn_sums: out = a + b (as gan_add_fwd: the gradient of a tensor with two consumers, e.g. the input
+ *             of a residual block, cyclegan_module.py:106-110) where that tensor was the output of the batch norm `bn`
+ *             (rows x c per group): the same launch leaves the block sums of that batch norm's backward over `out` in
+ *             bn_partial, for gan_bn_bwd_tiled(.., sums_ready = 1, ..).  out may be a or b.
  * All results are bit-identical to the separate entry points, except db through column-sum partials (same terms,
  * different grouping of the fp32 sum).  `op`: GAN_OP_*.  The shapes served are those for which
  * gan_bn_tile_blocks(groups, rows, c, backward) returns nb > 0 (channel count a multiple of 64, more than 1024 rows
@@ -233,6 +237,8 @@ int gan_bn_fwd_train_from_stats(const float* x, const float* gamma, const float*
 int gan_conv_dgrad_bn_sums(int op, const gan_conv_geom* g, const float* dy, const float* w, float* dx,
                            const gan_bn_saved* bn, float* bn_partial, void* ws, size_t ws_bytes,
                            gan_stream_t stream);
+int gan_add_bn_sums(const float* a, const float* b, float* out, const gan_bn_saved* bn, int rows, int c,
+                    float* bn_partial, gan_stream_t stream);
 int gan_bn_bwd_tiled(const float* x, const float* gamma, const float* beta, const float* save_mean,
                      const float* save_rstd, const float* dy, float* dx, float* dgamma, float* dbeta,
                      int accumulate, int groups, int rows, int c, int act, float act_param, float* sums_partial,

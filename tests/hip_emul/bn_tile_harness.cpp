@@ -153,7 +153,33 @@ static void backward_case(int groups, int rows, int c, int splits, int act, unsi
     EXPECT(same_bits(dx, dx2) && same_bits(dg, dg2) && same_bits(db, db2), "backward %d x %d x %d: apply differs", groups, rows, c);
 }
 
+// The gradient of a tensor with two consumers: the two addends presented as two "slabs" whose distance is the distance
+// of the two tensors (either sign), summed, stored and reduced in one launch.
+static void fan_out_case(int groups, int rows, int c, bool b_first, unsigned seed) {
+    std::mt19937 gen(seed);
+    TileBn ts;
+    EXPECT(bn_ride_plan(groups, rows, c, true, &ts), "no backward plan for %d x %d x %d", groups, rows, c);
+    const long elems = (long)groups * rows * c;
+    Buf a(elems), b(elems), sum0(elems), sum1(elems), x(elems), gamma(c), beta(c), mean(groups * c), rstd(groups * c);
+    a.fill(gen); b.fill(gen); x.fill(gen); gamma.fill(gen, 0.1f, 1.f); beta.fill(gen, 0.1f); mean.fill(gen, 0.1f); rstd.fill(gen, 0.05f, 1.f);
+    sum1.nan();
+    for (long i = 0; i < elems; ++i) sum0.p[i] = b_first ? b.p[i] + a.p[i] : a.p[i] + b.p[i];
+    Buf p0((size_t)2 * groups * ts.nb * c), p1((size_t)2 * groups * ts.nb * c);
+    p0.nan(); p1.nan();
+    BnRide r = BnRide{2, reinterpret_cast<float2*>(p0.p), ts, x.p, gamma.p, beta.p, mean.p, rstd.p, GAN_ACT_RELU, 0.2f};
+    EXPECT(launch_bn_ride(r, tensor_source(sum0.p), nullptr, "sums alone") == 0, "%s", error_buffer());
+    r.partial = reinterpret_cast<float2*>(p1.p);
+    const float* first = b_first ? b.p : a.p;
+    const float* second = b_first ? a.p : b.p;
+    EXPECT(launch_bn_ride(r, RowSource{first, sum1.p, nullptr, (long)(second - first), 2}, nullptr, "fan-out") == 0, "%s", error_buffer());
+    EXPECT(same_bits(sum0, sum1), "fan-out %d x %d x %d: sums of the addends differ", groups, rows, c);
+    EXPECT(same_bits(p0, p1), "fan-out %d x %d x %d: block sums differ", groups, rows, c);
+}
+
 int main() {
+    fan_out_case(1, 4096, 64, false, 21);
+    fan_out_case(2, 1296, 128, true, 22);
+    fan_out_case(3, 1300, 64, false, 23);
     forward_case(1, 2048, 64, 1, 1);
     forward_case(1, 1100, 128, 3, 2);
     forward_case(3, 1296, 64, 5, 3);           // row blocks of 62 rows: the row lanes take 3 or 4 rows each

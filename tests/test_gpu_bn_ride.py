@@ -225,6 +225,50 @@ def test_bias_gradient_from_column_sum_partials(L, op, splits, accumulate):
     torch.testing.assert_close(db1.double(), want, rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 4096, 256), (2, 1296, 128), (1, 16384, 64), (3, 1300, 64)])
+@pytest.mark.parametrize("act", [0, 2])
+@pytest.mark.parametrize("layout", ["a_first", "b_first", "in_place"])
+def test_fan_out_sum_with_backward_sums_is_bit_identical(L, shape, act, layout):
+    """gan_add_bn_sums (the gradient of a batch norm's output with two consumers, and that norm's backward block sums
+    in the same launch) followed by gan_bn_bwd_tiled against gan_add_fwd followed by gan_bn_bwd: every tensor bit for
+    bit, whichever addend lies first in memory, and with the sum stored over the first addend."""
+    groups, rows, c = shape
+    nb = int(L.lib.gan_bn_tile_blocks(groups, rows, c, 1))
+    assert nb > 0
+    n = groups * rows * c
+    torch.manual_seed(41)
+    pool = torch.randn(2 * n, device='cuda')
+    a, b = (pool[:n], pool[n:]) if layout != "b_first" else (pool[n:], pool[:n])
+    bn_x = torch.randn(n, device='cuda')
+    gamma, beta = torch.rand(c, device='cuda') + 0.5, torch.randn(c, device='cuda') * 0.1
+    mean, rstd = torch.randn(groups * c, device='cuda') * 0.1, torch.rand(groups * c, device='cuda') + 0.5
+    st = L.stream()
+    tail = (1, groups, rows, c, act, 0.2)
+    # separate launches
+    out0, dx0 = torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+    dg0, db0 = torch.ones(c, device='cuda'), torch.ones(c, device='cuda')
+    L.check(L.lib.gan_add_fwd(L.ptr(a), L.ptr(b), L.ptr(out0), n, st))
+    bp, bn_ = _bn_ws(L, groups, rows, c)
+    L.check(L.lib.gan_bn_bwd(L.ptr(bn_x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(out0), L.ptr(dx0),
+                             L.ptr(dg0), L.ptr(db0), *tail, bp, bn_, st))
+    # one launch for the sum and the block sums
+    out1 = a.clone() if layout == "in_place" else torch.full((n,), float('nan'), device='cuda')
+    first = out1 if layout == "in_place" else a
+    dx1 = torch.empty(n, device='cuda')
+    dg1, db1 = torch.ones(c, device='cuda'), torch.ones(c, device='cuda')
+    partial = torch.full((2 * groups * nb * c,), float('nan'), device='cuda')
+    saved = L.BnSaved(L.ptr(bn_x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), groups, act, 0.2)
+    L.check(L.lib.gan_add_bn_sums(L.ptr(first), L.ptr(b), L.ptr(out1), ctypes.byref(saved), rows, c, L.ptr(partial), st))
+    L.check(L.lib.gan_bn_bwd_tiled(L.ptr(bn_x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(out1), L.ptr(dx1),
+                                   L.ptr(dg1), L.ptr(db1), *tail, L.ptr(partial), 1, None, st))
+    torch.cuda.synchronize()
+    for u, v in ((out0, out1), (dx0, dx1), (dg0, dg1), (db0, db1)):
+        assert torch.isfinite(u).all() and torch.equal(u, v)
+    # shapes without a block decomposition and misaligned addends are refused
+    assert L.lib.gan_add_bn_sums(L.ptr(a), L.ptr(b), L.ptr(out1), ctypes.byref(saved), 128, c, L.ptr(partial), st) != 0
+    assert L.lib.gan_add_bn_sums(L.ptr(a), L.ptr(pool[1:n + 1]), L.ptr(out1), ctypes.byref(saved), rows, c, L.ptr(partial), st) != 0
+
+
 def test_riding_entry_points_refuse_what_they_cannot_serve(L):
     from gpu_util import geom_for
     g = geom_for(8, 32, 32, 16, 64, 5, 2, 'SAME')
