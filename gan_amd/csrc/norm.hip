@@ -718,20 +718,43 @@ __global__ __launch_bounds__(256) void bn_tile_stats_kernel(const float* __restr
     }
 }
 
+// The apply kernels of both directions begin with a chain of dependent latencies (block partials -> LDS merge ->
+// statistics) before they can use a single row.  The first kTilePre rows of every row lane (all of them for a row block
+// of 64 rows) are therefore requested BEFORE that chain and wait in registers: the two latencies overlap.
+constexpr int kTilePre = 4;
+
+__device__ __forceinline__ void tile_bn_prefetch(const float4* p, int r0, int r1, int rl, int c4, float4 (&pre)[kTilePre]) {
+#pragma unroll
+    for (int j = 0; j < kTilePre; ++j) {
+        const int r = r0 + rl + 16 * j;
+        pre[j] = r < r1 ? p[(long)r * c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ void tile_bn_apply_row(float4 v, const float4* rp, float4* yp, long at, float4 mean, float4 rstd,
+                                                  float4 ga, float4 be, float act_param) {
+    float4 o;
+    o.x = apply_act((v.x - mean.x) * rstd.x * ga.x + be.x, ACT, act_param);
+    o.y = apply_act((v.y - mean.y) * rstd.y * ga.y + be.y, ACT, act_param);
+    o.z = apply_act((v.z - mean.z) * rstd.z * ga.z + be.z, ACT, act_param);
+    o.w = apply_act((v.w - mean.w) * rstd.w * ga.w + be.w, ACT, act_param);
+    if (rp) o = f4_add(o, rp[at]);
+    yp[at] = o;
+}
+
 template <int ACT>
 __device__ __forceinline__ void tile_bn_apply_rows(const float4* xp, const float4* rp, float4* yp, int r0, int r1, int rl, int c4,
-                                                   float4 mean, float4 rstd, float4 ga, float4 be, float act_param) {
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += 16) {
-        const float4 v = xp[(long)r * c4];
-        float4 o;
-        o.x = apply_act((v.x - mean.x) * rstd.x * ga.x + be.x, ACT, act_param);
-        o.y = apply_act((v.y - mean.y) * rstd.y * ga.y + be.y, ACT, act_param);
-        o.z = apply_act((v.z - mean.z) * rstd.z * ga.z + be.z, ACT, act_param);
-        o.w = apply_act((v.w - mean.w) * rstd.w * ga.w + be.w, ACT, act_param);
-        if (rp) o = f4_add(o, rp[(long)r * c4]);
-        yp[(long)r * c4] = o;
+                                                   float4 mean, float4 rstd, float4 ga, float4 be, float act_param,
+                                                   const float4 (&pre)[kTilePre]) {
+#pragma unroll
+    for (int j = 0; j < kTilePre; ++j) {
+        const int r = r0 + rl + 16 * j;
+        if (r < r1) tile_bn_apply_row<ACT>(pre[j], rp, yp, (long)r * c4, mean, rstd, ga, be, act_param);
     }
+#pragma unroll 4
+    for (int r = r0 + rl + 16 * kTilePre; r < r1; r += 16)
+        tile_bn_apply_row<ACT>(xp[(long)r * c4], rp, yp, (long)r * c4, mean, rstd, ga, be, act_param);
 }
 
 // The activation is the same for every element of a launch: the row loops are instantiated per activation and the
@@ -757,6 +780,11 @@ __global__ __launch_bounds__(256) void bn_tile_apply_kernel(const float* __restr
     const int rb = blockIdx.x, ch0 = blockIdx.y * 64, grp = blockIdx.z;
     const int c4 = s.c >> 2, q = (ch0 >> 2) + quad;
     const float4 ga = reinterpret_cast<const float4*>(gamma)[q], be = reinterpret_cast<const float4*>(beta)[q];
+    const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
+    const long base = ((long)grp * s.rows) * c4 + q;
+    const float4* xp = reinterpret_cast<const float4*>(x) + base;
+    float4 pre[kTilePre];
+    tile_bn_prefetch(xp, r0, r1, rl, c4, pre);
     const bool moves = (moving_mean != nullptr && rb == 0 && grp == 0);
     float4 mm = make_float4(0.f, 0.f, 0.f, 0.f), mv = mm;
     if (moves) {
@@ -788,12 +816,9 @@ __global__ __launch_bounds__(256) void bn_tile_apply_kernel(const float* __restr
             reinterpret_cast<float4*>(moving_var)[q] = mv;
         }
     }
-    const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
-    const long base = ((long)grp * s.rows) * c4 + q;
-    const float4* xp = reinterpret_cast<const float4*>(x) + base;
     const float4* rp = residual ? reinterpret_cast<const float4*>(residual) + base : nullptr;
     float4* yp = reinterpret_cast<float4*>(y) + base;
-    GAN_ACT_DISPATCH(act, (tile_bn_apply_rows<ACT>(xp, rp, yp, r0, r1, rl, c4, mean, rstd, ga, be, act_param)));
+    GAN_ACT_DISPATCH(act, (tile_bn_apply_rows<ACT>(xp, rp, yp, r0, r1, rl, c4, mean, rstd, ga, be, act_param, pre)));
 }
 
 template <int ACT>
@@ -824,20 +849,34 @@ __device__ __forceinline__ void tile_bn_bwd_sum_rows(const float4* xp, const flo
 }
 
 template <int ACT>
+__device__ __forceinline__ void tile_bn_bwd_apply_row(float4 xv, float4 dv, float4* op, long at, float4 mu, float4 rs, float4 ga,
+                                                      float4 be, float act_param, float4 a0, float4 a1, float inv_rows,
+                                                      float4& colsum) {
+    float4 xh, o;
+    const float4 dz = dz4<ACT>(xv, dv, mu, rs, ga, be, act_param, xh);
+    o.x = ga.x * rs.x * (dz.x - a0.x * inv_rows - xh.x * (a1.x * inv_rows));
+    o.y = ga.y * rs.y * (dz.y - a0.y * inv_rows - xh.y * (a1.y * inv_rows));
+    o.z = ga.z * rs.z * (dz.z - a0.z * inv_rows - xh.z * (a1.z * inv_rows));
+    o.w = ga.w * rs.w * (dz.w - a0.w * inv_rows - xh.w * (a1.w * inv_rows));
+    op[at] = o;
+    colsum = f4_add(colsum, o);
+}
+
+// (pre_x / pre_d: the first kTilePre rows of this row lane, requested before the block sums were merged)
+template <int ACT>
 __device__ __forceinline__ void tile_bn_bwd_apply_rows(const float4* xp, const float4* dp, float4* op, int r0, int r1, int rl,
                                                        int c4, float4 mu, float4 rs, float4 ga, float4 be, float act_param,
-                                                       float4 a0, float4 a1, float inv_rows, float4& colsum) {
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += 16) {
-        float4 xh, o;
-        const float4 dz = dz4<ACT>(xp[(long)r * c4], dp[(long)r * c4], mu, rs, ga, be, act_param, xh);
-        o.x = ga.x * rs.x * (dz.x - a0.x * inv_rows - xh.x * (a1.x * inv_rows));
-        o.y = ga.y * rs.y * (dz.y - a0.y * inv_rows - xh.y * (a1.y * inv_rows));
-        o.z = ga.z * rs.z * (dz.z - a0.z * inv_rows - xh.z * (a1.z * inv_rows));
-        o.w = ga.w * rs.w * (dz.w - a0.w * inv_rows - xh.w * (a1.w * inv_rows));
-        op[(long)r * c4] = o;
-        colsum = f4_add(colsum, o);
+                                                       float4 a0, float4 a1, float inv_rows, float4& colsum,
+                                                       const float4 (&pre_x)[kTilePre], const float4 (&pre_d)[kTilePre]) {
+#pragma unroll
+    for (int j = 0; j < kTilePre; ++j) {
+        const int r = r0 + rl + 16 * j;
+        if (r < r1) tile_bn_bwd_apply_row<ACT>(pre_x[j], pre_d[j], op, (long)r * c4, mu, rs, ga, be, act_param, a0, a1, inv_rows, colsum);
     }
+#pragma unroll 4
+    for (int r = r0 + rl + 16 * kTilePre; r < r1; r += 16)
+        tile_bn_bwd_apply_row<ACT>(xp[(long)r * c4], dp[(long)r * c4], op, (long)r * c4, mu, rs, ga, be, act_param, a0, a1, inv_rows,
+                                   colsum);
 }
 
 template <int KIND>
@@ -886,6 +925,15 @@ __global__ __launch_bounds__(256) void bn_tile_bwd_apply_kernel(const float* __r
     const float4 mu = reinterpret_cast<const float4*>(mean + (long)grp * s.c)[q];
     const float4 rs = reinterpret_cast<const float4*>(rstd + (long)grp * s.c)[q];
     const float4 ga = reinterpret_cast<const float4*>(gamma)[q], be = reinterpret_cast<const float4*>(beta)[q];
+    const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
+    const long base = ((long)grp * s.rows) * c4 + q;
+    const float4* xp = reinterpret_cast<const float4*>(x) + base;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+    float4 pre_x[kTilePre], pre_d[kTilePre];
+    if (dx != nullptr) {        // (uniform over the launch)
+        tile_bn_prefetch(xp, r0, r1, rl, c4, pre_x);
+        tile_bn_prefetch(dp, r0, r1, rl, c4, pre_d);
+    }
     float4 a0, a1;
     tile_bn_sums<false>(partial, s, grp, ch0, quad, rl, zero, red, a0, a1);
     if (rb == 0 && grp == 0 && (dgamma != nullptr || dbeta != nullptr)) {
@@ -903,14 +951,10 @@ __global__ __launch_bounds__(256) void bn_tile_bwd_apply_kernel(const float* __r
         }
     }
     if (dx == nullptr) return;
-    const int r0 = rb * s.rpb, r1 = min(s.rows, r0 + s.rpb);
-    const long base = ((long)grp * s.rows) * c4 + q;
-    const float4* xp = reinterpret_cast<const float4*>(x) + base;
-    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
     float4* op = reinterpret_cast<float4*>(dx) + base;
     float4 cs = zero;
     GAN_ACT_DISPATCH(act, (tile_bn_bwd_apply_rows<ACT>(xp, dp, op, r0, r1, rl, c4, mu, rs, ga, be, act_param, a0, a1,
-                                                       1.0f / (float)s.rows, cs)));
+                                                       1.0f / (float)s.rows, cs, pre_x, pre_d)));
     if (colsum_partial == nullptr) return;      // (uniform over the launch)
     // the column sum of the rows this workgroup stored: first stage of the bias gradient of the layer in front
     __syncthreads();
