@@ -78,6 +78,11 @@ def build_parser():
     parser.add_argument('--dataset_cache_gb', type=float, default=32.0,
                         help='DCGAN image files: keep the cropped / resized uint8 images in GPU memory after the first '
                              'epoch when they fit in this many GiB (0: decode the files every epoch)')
+    parser.add_argument('--contraction_plans', default=None,
+                        help='JSON file of pinned contraction plans (gan_amd.autotune.save / tools/insitu_tune.py): every '
+                             'run then launches the same kernels with the same split-K summation order; layer shapes the '
+                             'file does not hold keep the library\'s heuristic plan (or are tuned on first use when '
+                             'GAN_HIP_AUTOTUNE=1)')
     parser.add_argument('--prefetch_batches', type=int, default=4,
                         help='batches the host input pipeline prepares ahead of the GPU (num_preprocess_threads decode the files)')
     return parser
@@ -131,6 +136,9 @@ def main(opts):
     print('sample_dir = {}'.format(opts.sample_dir))
     os.makedirs(opts.sample_dir, exist_ok=True)
 
+    if getattr(opts, 'contraction_plans', None):
+        from . import autotune
+        autotune.load(opts.contraction_plans)
     sess = None     # the reference's tf.Session has no counterpart: kernels launch on the current HIP stream
     # one process per GPU under torch.distributed.run: every rank a replica, gradients summed per update
     from .dp import init_from_env

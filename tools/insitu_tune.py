@@ -4,12 +4,12 @@
 gan_amd.autotune times a layer pass alone, launch after launch, with its operands hot in the caches.  Inside a training
 iteration the same pass meets a cold filter (Adam has just rewritten it), competes with the launches around it for the
 memory system, and its split-K slabs are read back by a reduction that may carry a batch-norm reduction.  This tool
-starts from a pinned plan file and walks over the (geometry, mode) pairs the DCGAN-64 iteration really issues, heaviest
+starts from a pinned plan file (or the tuner's choices) and walks over the (geometry, mode) pairs the iteration really issues, heaviest
 first: for each it captures the iteration with a neighbouring plan (other split-K factors, the other bf16 tile
 configurations, the four tile orders), replays it, and keeps the plan only if the iteration got faster twice in a row.
 The result is written in gan_amd.autotune's format.
 
-    python tools/insitu_tune.py --plans profiles/r03_plans.json --out gpurun_out/plans_insitu.json [--budget-s 420]
+    python tools/insitu_tune.py [--model dcgan|t2i|cyclegan] [--plans FILE] --out gpurun_out/plans_insitu.json [--budget-s 420]
 """
 import argparse
 import ctypes
@@ -39,7 +39,9 @@ def plan_of(mode, g):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--plans", default=bench.PLANS_FILE)
+    ap.add_argument("--plans", default=None, help="plan file to start from (default: profiles/r03_plans.json for dcgan, else "
+                                                  "the plans gan_amd.autotune picks at start-up)")
+    ap.add_argument("--model", default="dcgan", choices=["dcgan", "t2i", "cyclegan"])
     ap.add_argument("--out", required=True)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--budget-s", type=float, default=420.0)
@@ -47,9 +49,12 @@ def main():
     args = ap.parse_args()
     torch.cuda.set_device(0)
     autotune.enable(True)
-    autotune.load(args.plans)
-    model, batch, make_runner = build("dcgan", np.random.default_rng(1000))
-    optims = [model.d_optim, model.g_optim]
+    plans = args.plans or (bench.PLANS_FILE if args.model == "dcgan" else None)
+    if plans:
+        autotune.load(plans)
+    model, batch, make_runner = build(args.model, np.random.default_rng(1000))
+    optims = [o for o in (getattr(model, n, None) for n in ("d_optim", "g_optim", "da_optim", "db_optim", "g_a2b_optim", "g_b2a_optim"))
+              if o is not None]
     model.train_iteration(*batch)
     torch.cuda.synchronize()
     start = graph.model_state_snapshot(model.store, optims)
@@ -65,6 +70,8 @@ def main():
             _lib.check(L.gan_linear_as_conv_geom(shape[0], shape[1], shape[2], ctypes.byref(g)))
         else:
             g = _lib.ConvGeom(*shape)
+            if name == "gan_conv2d_dgrad_reflect":      # its contraction runs on the geometry of the reflect-padded image
+                g.hb, g.wb, g.pt, g.pl = g.hb + 2 * g.pt, g.wb + 2 * g.pl, 0, 0
         key = (bench.ENTRY_MODE[name],) + tuple(g.key())
         pairs.setdefault(key, [g, 0.0])[1] += e0.elapsed_time(e1)
     order = sorted(pairs.items(), key=lambda kv: -kv[1][1])

@@ -53,8 +53,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
+    ap.add_argument("--plans", default=None,
+                    help="JSON file of pinned contraction plans, loaded before the models are built (default for cyclegan: "
+                         "profiles/r03_plans_cyclegan.json, found by tools/insitu_tune.py; 'none' tunes at start-up)")
     args = ap.parse_args()
     autotune.enable(not args.no_autotune)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    plans = args.plans
+    if plans is None and args.model == "cyclegan" and not args.no_autotune:
+        plans = os.path.join(root, "profiles", "r03_plans_cyclegan.json")
+    if plans and plans != "none" and os.path.exists(plans):
+        autotune.load(plans)
     rng = np.random.default_rng(0)
     P = build_parser()
     if args.model in ("mnist", "all"):
