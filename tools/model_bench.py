@@ -54,20 +54,22 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's heuristic contraction plans")
     ap.add_argument("--plans", default=None,
-                    help="JSON file of pinned contraction plans, loaded before the models are built (default for cyclegan: "
-                         "profiles/r03_plans_cyclegan.json, found by tools/insitu_tune.py; 'none' tunes at start-up)")
+                    help="JSON file of pinned contraction plans, loaded before a model is built (default: "
+                         "profiles/r03_plans_<model>.json where it exists, found by tools/insitu_tune.py; 'none' tunes every "
+                         "layer shape at start-up)")
     args = ap.parse_args()
     autotune.enable(not args.no_autotune)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    plans = args.plans
-    if plans is None and args.model == "cyclegan" and not args.no_autotune:
-        plans = os.path.join(root, "profiles", "r03_plans_cyclegan.json")
-    if plans and plans != "none" and os.path.exists(plans):
-        autotune.load(plans)
+
+    def pin_plans(model):
+        plans = args.plans or os.path.join(root, "profiles", "r03_plans_%s.json" % model)
+        if not args.no_autotune and plans != "none" and os.path.exists(plans):
+            autotune.load(plans)
     rng = np.random.default_rng(0)
     P = build_parser()
     if args.model in ("mnist", "all"):
         from gan_amd.dcgan import DCGAN
+        pin_plans("mnist")
         o = P.parse_args("--dataset mnist --input_height 28 --output_height 28".split())
         o.input_width, o.output_width, o.y_dim, o.c_dim = 28, 28, 10, 1
         m = DCGAN(None, o, load_data=False)
@@ -79,6 +81,7 @@ def main():
                           "images_per_s": round(64 / dt, 1), "losses": vals}), flush=True)
     if args.model in ("text2image", "all"):
         from gan_amd.text2image import Text2Image
+        pin_plans("text2image")
         o = P.parse_args("--dataset flowers --input_height 64 --model Text2Image --textEncoder DSSJE".split())
         m = Text2Image(None, o)
         inp = [dev(rng.uniform(0, 1, (64, 64, 64, 3))), dev(rng.uniform(0, 1, (64, 64, 64, 3))),
@@ -89,6 +92,7 @@ def main():
                           "images_per_s": round(64 / dt, 1), "losses": vals}), flush=True)
     if args.model in ("cyclegan", "all"):
         from gan_amd.cyclegan import CycleGAN
+        pin_plans("cyclegan")
         o = P.parse_args("--model CycleGAN --batch_size 1 --dataset horse2zebra".split())     # image pool of 50
         m = CycleGAN(None, o)
         inp = [dev(rng.uniform(-1, 1, (1, 256, 256, 6)))]
