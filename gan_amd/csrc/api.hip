@@ -71,6 +71,7 @@ Knobs& knobs() {
         r.separate_colsum = getenv("GAN_HIP_SEPARATE_COLSUM") != nullptr;
         r.tile_order = env_int("GAN_HIP_TILE_ORDER", 0);
         r.rgb_gather = env_int("GAN_HIP_RGB_GATHER", 1);
+        r.row_gather_any = env_int("GAN_HIP_ROW_GATHER_ANY", 1);
         r.exact_f32 = env_flag("GAN_HIP_EXACT_F32");
         r.no_carry = getenv("GAN_HIP_NO_CARRY") != nullptr;
         r.no_bn_ride = env_int("GAN_HIP_NO_BN_RIDE", 0);
@@ -623,6 +624,7 @@ extern "C" int gan_knob_set(const char* name, int value) {
     else if (!strcmp(name, "separate_colsum")) k.separate_colsum = value != 0;
     else if (!strcmp(name, "tile_order")) k.tile_order = value;
     else if (!strcmp(name, "rgb_gather")) k.rgb_gather = value;
+    else if (!strcmp(name, "row_gather_any")) k.row_gather_any = value;
     else if (!strcmp(name, "no_carry")) k.no_carry = value != 0;
     else if (!strcmp(name, "no_bn_ride")) k.no_bn_ride = value;
     else if (!strcmp(name, "rgb_direct")) k.rgb_direct = value != 0;

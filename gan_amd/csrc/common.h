@@ -36,6 +36,7 @@ struct Knobs {
     int three_launch_bn;  // GAN_HIP_THREE_LAUNCH_BN: every batch norm on the general three-launch path
     int two_launch_bn;    // GAN_HIP_TWO_LAUNCH_BN: 0 keeps batch norms above 1024 rows per group on the three-launch path
     int separate_colsum;  // GAN_HIP_SEPARATE_COLSUM: bias gradients as launches of their own
+    int row_gather_any;   // GAN_HIP_ROW_GATHER_ANY: the filter-row gather for every channel count that is no multiple of 4 (default 1)
     int rgb_gather;       // GAN_HIP_RGB_GATHER: filter-row gather for 3-channel images: 1 FPROP and WGRAD, 2 WGRAD only, 0 off
     int tile_order;       // GAN_HIP_TILE_ORDER: 0 chosen per launch, 1 launch order, 2 by row tile, 3 by k range
     int exact_f32;      // GAN_HIP_EXACT_F32: default of gan_set_exact_f32

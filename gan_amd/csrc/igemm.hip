@@ -919,10 +919,15 @@ static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15)
 // of 4 and both operands below 4 GB (a_bytes / b_bytes are 0 beyond that).
 // RGB layers (FPROP / WGRAD over a 3-channel big image) take the split kernel's filter-row gather: slices per
 // filter row, or 0 when the geometry does not qualify (a run of kw * 3 floats must fit two 16-deep slices).
+// The same gather serves every big image whose channel count is no multiple of 4 (the 1 / 11 / 21-channel layers of
+// the y-conditioned MNIST model): a filter row's kw * cb values are one contiguous run whatever cb is (knob
+// row_gather_any = 0 keeps those layers on the fp32 kernel).
 static int row3_slices(int mode, const gan_conv_geom& g) {
-    if (mode == MODE_TPROP || g.cb != 3 || g.cs % 4 != 0 || g.kw * 3 > 32) return 0;
+    if (mode == MODE_TPROP || g.cb % 4 == 0) return 0;
+    const bool rgb = g.cb == 3 && g.cs % 4 == 0 && g.kw * 3 <= 32;
+    if (!rgb && (!knobs().row_gather_any || g.kw * g.cb > 128)) return 0;
     if (knobs().rgb_gather == 0 || (knobs().rgb_gather == 2 && mode == MODE_FPROP)) return 0;
-    return (g.kw * 3 + 15) / 16;
+    return (g.kw * g.cb + 15) / 16;
 }
 
 static bool split_eligible(int mode, const IgemmArgs& a) {
@@ -1316,6 +1321,7 @@ IgemmArgs make_args(int mode, const gan_conv_geom& g, const float* a, const floa
     r.epi = no_epilogue();
     r.reflect = 0;
     r.row3_spr = 0;
+    r.row3_mul = (65536 + g.cb - 1) / g.cb;
     r.own_blocks = 0x7fffffff;
 #ifdef GAN_PHASE_STAMPS
     r.stamps = g_debug_stamps;

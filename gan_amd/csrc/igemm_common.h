@@ -55,7 +55,9 @@ struct IgemmArgs {
     Epilogue epi;  // applied where the final value is stored: here when splits == 1, else by the slab reduction
     int reflect;   // FPROP / WGRAD: taps that fall outside the big image read its mirror image (tf.pad REFLECT
                    // by pt / pl in front of a VALID convolution) instead of zeros
-    int row3_spr;  // > 0: filter-row gather of a 3-channel big image (igemm_split.h, ROW3), slices per filter row
+    int row3_spr;  // > 0: filter-row gather of a big image whose channel count is no multiple of 4 (igemm_split.h, ROW3),
+                   // slices per filter row
+    int row3_mul;  // ceil(65536 / cb): (e * row3_mul) >> 16 = e / cb for the run elements e < 144
     int grid_mt, grid_nt, grid_z;  // row tiles, column tiles, (parity classes x k splits) of the one-dimensional grid
     int xcd_order;                 // tile_of_workgroup: 0 / 3 launch order (k range / row tile fastest), 1 / 2 XCD-aware
     // Workgroups beyond own_blocks carry the last stage of a bias-gradient column sum (its partial sums were left by

@@ -79,10 +79,11 @@ __device__ __forceinline__ int unpermute(int pos) {
 // second group hands its accumulators to the first through LDS at the end.  A launch then needs half as many
 // split-K slabs (written once, read once by the reduction) for the same number of waves on the chip.
 //
-// ROW3 (FPROP / WGRAD of a 3-channel big image: the layers that read or write RGB pixels).  The gather axis
-// (tap, channel) is re-indexed per FILTER ROW: the kw * 3 values one filter row touches are one contiguous run of
+// ROW3 (FPROP / WGRAD of a big image whose channel count cb is no multiple of 4: the 3-channel layers that read or
+// write RGB pixels, the 1 / 11 / 21-channel layers of the y-conditioned MNIST model).  The gather axis
+// (tap, channel) is re-indexed per FILTER ROW: the kw * cb values one filter row touches are one contiguous run of
 // floats in memory, padded to p.row3_spr slices of 16 (the pad multiplies zeros).  Element e of the run is column
-// x0 + e / 3, channel e % 3, loaded as one dword with its own range check: neither a per-element tap decode nor
+// x0 + e / cb, channel e % cb, loaded as one dword with its own range check: neither a per-element tap decode nor
 // vector alignment is needed.  FPROP: the virtual K is kh * spr * 16; WGRAD: the virtual M.
 //
 // REFLECT (FPROP / WGRAD): taps outside the big image read its mirror image (the `reflect` flag of the fp32 kernel as
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     const int b_kq = ((btc / BN) << 1) | (btc & 1);
 
     // filter-row gather: the run elements of this thread (FPROP: 4 consecutive ones per slice half; WGRAD: its row pair)
-    const int r3_len = ROW3 ? g.kw * 3 : 0;          // floats of a filter row
+    const int r3_len = ROW3 ? g.kw * g.cb : 0;       // floats of a filter row
     const int r3_rows = ROW3 ? p.row3_spr * 16 : 1;  // virtual rows (WGRAD) / k (FPROP) per filter row
     int w_ta = 0, w_e = 0;                           // WGRAD: filter row and run element of the thread's first row
     if constexpr (ROW3 && MODE == MODE_WGRAD) {
@@ -271,15 +272,15 @@ __global__ __launch_bounds__(256 * KG) void igemm_split_kernel(const IgemmArgs p
     auto ld1 = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off, float& dst) {
         dst = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
     };
-    // byte offset of run element e (column x0 + e / 3, channel e % 3) of image row `rowbase` (in pixels), or out of range
+    // byte offset of run element e (column x0 + e / cb, channel e % cb) of image row `rowbase` (in pixels), or out of range
     auto r3_off = [&](int rowbase, int x0, int e, bool ok) -> unsigned {
-        const int tc = (e * 11) >> 5;      // e / 3 for e < 32
+        const int tc = (int)(((unsigned)e * (unsigned)p.row3_mul) >> 16);      // e / cb (e < 144)
         int col = x0 + tc;
         if constexpr (REFLECT) col = reflect_at(col, g.wb);
         ok = ok & (e < r3_len) & ((unsigned)col < (unsigned)g.wb);
         // (the offset is worked out unconditionally: with the arithmetic inside the conditional expression the compiler
         // keeps a branch around it, and a branch splits the slice loop's basic block)
-        const unsigned off = (unsigned)((rowbase + col) * 3 + (e - 3 * tc)) * 4u;
+        const unsigned off = (unsigned)((rowbase + col) * g.cb + (e - g.cb * tc)) * 4u;
         return ok ? off : kOutOfRange;
     };
 

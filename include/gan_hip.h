@@ -388,6 +388,9 @@ int gan_get_exact_f32(void);
  *   "rgb_gather"      GAN_HIP_RGB_GATHER=<0..2>  filter-row gather of the bf16 kernels for 3-channel images: 1 (default)
  *                                                forward and weight gradient, 2 weight gradient only, 0 off (those
  *                                                layers then run on the fp32 MFMA kernel)
+ *   "row_gather_any"  GAN_HIP_ROW_GATHER_ANY=0   the same gather for every other channel count that is no multiple of 4
+ *                                                (the 1 / 11 / 21-channel layers of the y-conditioned MNIST model): 0
+ *                                                keeps those layers on the fp32 MFMA kernel
  *   "no_bn_ride"      GAN_HIP_NO_BN_RIDE=<1|2>
  *                                                1: gan_bn_tile_blocks reports 0, so callers keep the separate batch-norm
  *                                                launches; 2: the reductions of gan_conv_fwd_bn_stats / gan_conv_dgrad_bn_sums

@@ -32,6 +32,6 @@ def _library_knobs_back_to_default(request):
         return
     from gan_amd._lib import knob_set
     for name, unset in (("force_cfg", -1), ("force_splits", 0), ("no_thin", 0), ("slow_gather", 0),
-                        ("scalar_epilogue", 0), ("three_launch_bn", 0), ("two_launch_bn", 1), ("separate_colsum", 0), ("tile_order", 0), ("rgb_gather", 1),
+                        ("scalar_epilogue", 0), ("three_launch_bn", 0), ("two_launch_bn", 1), ("separate_colsum", 0), ("tile_order", 0), ("rgb_gather", 1), ("row_gather_any", 1),
                         ("no_carry", 0), ("no_bn_ride", 0), ("rgb_direct", 1)):
         knob_set(name, unset)

@@ -117,6 +117,21 @@ def test_conv2d_every_tile_config_and_split(L, cfg, splits):
     _conv_case(L, (2, 9, 9, 5, 7, 3, 1, 'SAME'), cfg, splits)      # odd channels: 4..6 fall back to 0..2
 
 
+@pytest.mark.parametrize("case", [(3, 28, 28, 11, 11, 5, 2, 'SAME'),      # MNIST d_h0: runs of 55 floats, 4 slices per filter row
+                                  (3, 14, 14, 21, 74, 5, 2, 'SAME'),      # MNIST d_h1: runs of 105 floats, 7 slices
+                                  (3, 28, 28, 1, 138, 5, 2, 'SAME'),      # MNIST g_h3 (as a convolution): runs of 5 floats
+                                  (2, 13, 17, 6, 10, 7, 1, 'SAME'),       # 7 x 7, stride 1, ragged image
+                                  (2, 11, 9, 18, 5, 7, 2, 'VALID'),       # runs of 126 floats: the longest run served
+                                  (1, 12, 12, 19, 8, 7, 1, 'SAME')])      # runs of 133 floats: stays on the fp32 kernel
+@pytest.mark.parametrize("cfg", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("splits", [1, 2])
+def test_filter_row_gather_for_any_channel_count(L, case, cfg, splits):
+    """Forward and weight gradient over a big image whose channel count is no multiple of 4 on the bf16 kernels: a
+    filter row's kw x cb values are gathered as one contiguous run, element by element (every bf16 tile
+    configuration, with and without split-K slabs), against the float64 oracle."""
+    _conv_case(L, case, cfg, splits)
+
+
 @pytest.mark.parametrize("case,cfg,splits", [((3, 28, 28, 1, 138, 5, 2, 'SAME'), 2, 20),     # dw: 3450 elements
                                              ((3, 28, 28, 11, 11, 5, 2, 'SAME'), 3, 16),    # dw: 3025, dx: 25872
                                              ((2, 14, 14, 128, 138, 5, 2, 'SAME'), 5, 24)])

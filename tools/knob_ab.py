@@ -21,7 +21,7 @@ from gan_amd import _lib, autotune, ops  # noqa: E402
 
 
 DEFAULTS = {"force_cfg": -1, "force_splits": 0, "no_thin": 0, "slow_gather": 0, "scalar_epilogue": 0, "three_launch_bn": 0,
-            "two_launch_bn": 1, "separate_colsum": 0, "tile_order": 0, "rgb_gather": 1, "no_carry": 0, "no_bn_ride": 0, "rgb_direct": 1,
+            "two_launch_bn": 1, "separate_colsum": 0, "tile_order": 0, "rgb_gather": 1, "row_gather_any": 1, "no_carry": 0, "no_bn_ride": 0, "rgb_direct": 1,
             "ride_parts": 15, "taps": 1}     # (host side, gan_amd.ops.RIDE_PARTS: 1 forward statistics + 2 backward sums + 4 column sums
                                               #  + 8 backward sums in the launch that adds the gradients of a fan-out)
 
