@@ -1360,7 +1360,8 @@ int plan_set(int mode, const gan_conv_geom& g, int cfg, int splits) {
         const IgemmArgs a = make_args(mode, g, nullptr, nullptr, nullptr, nullptr, 0);
         GAN_CHECK_ARG(split_eligible(mode, a),
                       "gan_conv_plan_set: tile configuration %d (bf16 matrix pipe) needs a gathered-image channel count "
-                      "that is a multiple of 4 and operands below 4 GB; this geometry runs configurations 0..3", cfg % kOrderStride);
+                      "that is a multiple of 4 (forward / weight gradient: or filter rows of at most 128 floats; transposed: "
+                      "or an even count) and operands below 4 GB; this geometry runs configurations 0..3", cfg % kOrderStride);
     }
     std::lock_guard<std::mutex> lock(g_plan_mu);
     if (cfg < 0) plan_table().erase(plan_key(mode, g));

@@ -108,10 +108,16 @@ def test_plan_pinning_is_host_side_bookkeeping():
     assert get(0)[:2] == (1, 4)        # two k groups per workgroup fall back to one: twice the slabs
     L.lib.gan_set_exact_f32(0)
     L.check(L.lib.gan_conv_plan_set(0, gp, -1, 0))
-    godd = L.conv_geom(8, 16, 16, 6, 8, 8, 10, 5, 5, 2, 2, 1, 1)
-    # a geometry that cannot take the split kernels (gathered-image channel count no multiple of 4): the pin is refused, so that
-    # what is pinned is exactly what runs
+    godd = L.conv_geom(8, 16, 16, 27, 8, 8, 10, 5, 5, 2, 2, 1, 1)
+    # a geometry that cannot take the split kernels (gathered-image channel count no multiple of 4 and filter rows of
+    # 5 x 27 = 135 floats, longer than the filter-row gather serves): the pin is refused, so that what is pinned is
+    # exactly what runs
     assert L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 6, 1) != 0 and b"multiple of 4" in L.lib.gan_last_error()
+    # ... while 6 channels (rows of 30 floats) take them through the filter-row gather; the transposed mode needs an even count
+    gsix = L.conv_geom(8, 16, 16, 6, 8, 8, 9, 5, 5, 2, 2, 1, 1)
+    L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(gsix), 6, 1))
+    L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(gsix), -1, 0))
+    assert L.lib.gan_conv_plan_set(1, ctypes.byref(gsix), 6, 1) != 0
     L.check(L.lib.gan_conv_plan_set(0, ctypes.byref(godd), 2, 1))
     L.check(L.lib.gan_conv_plan_get(0, ctypes.byref(godd), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
     assert c.value == 2
