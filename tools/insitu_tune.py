@@ -135,7 +135,7 @@ def main():
             if L.gan_conv_plan_set(mode, ctypes.byref(g), c + autotune.ORDER_STRIDE * o, s) != 0:
                 continue
             t = measure()
-            verdict = ""
+            note = ""
             if t < best_t * (1.0 - args.min_gain):
                 # confirm: the incumbent and the candidate once more each
                 bp = best_plan
@@ -145,10 +145,10 @@ def main():
                 t2 = measure()
                 if t2 < t_inc * (1.0 - args.min_gain):
                     best_plan, best_t = (c, s, o), min(t, t2)
-                    verdict = "  <- kept (incumbent again %.4f, candidate again %.4f)" % (t_inc, t2)
+                    note = "  <- kept (incumbent again %.4f, candidate again %.4f)" % (t_inc, t2)
                 else:
-                    verdict = "  (not confirmed: incumbent again %.4f, candidate again %.4f)" % (t_inc, t2)
-            print("    cfg %d splits %3d order %d: %.4f ms/step%s" % (c, s, o, t, verdict), flush=True)
+                    note = "  (not confirmed: incumbent again %.4f, candidate again %.4f)" % (t_inc, t2)
+            print("    cfg %d splits %3d order %d: %.4f ms/step%s" % (c, s, o, t, note), flush=True)
         _lib.check(L.gan_conv_plan_set(mode, ctypes.byref(g), best_plan[0] + autotune.ORDER_STRIDE * best_plan[2], best_plan[1]))
         if best_plan != (cfg, splits, tile_order):
             log.append({"mode": mode, "geom": list(g.key()), "from": [cfg, splits, tile_order], "to": list(best_plan),
