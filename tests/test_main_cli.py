@@ -56,6 +56,45 @@ def test_models_train_from_the_command_line_on_synthetic_data(argv, tmp_path):
 
 
 @pytest.mark.gpu
+def test_pinned_contraction_plans_reproduce_a_run_bit_for_bit(tmp_path):
+    """--contraction_plans: a run that pins the plans another run ended up with (gan_amd.autotune.save) launches the same
+    kernels with the same split-K summation order, so its losses are the first run's bit for bit; the plans come back
+    from the library as the file states them."""
+    import ctypes
+    import json
+    from gan_amd import _lib as L, autotune
+    from gan_amd.main import main
+    argv = ("--model DCGAN --dataset celebA --output_height 32 --batch_size 16 --gf_dim 16 --df_dim 16 --z_dim 16 "
+            "--synthetic_iters 2 --use_graph false").split()
+    dirs = lambda tag: ["--checkpoint_dir", str(tmp_path / ("c" + tag)), "--sample_dir", str(tmp_path / ("s" + tag))]
+    plans = str(tmp_path / "plans.json")
+    autotune.reset()
+    autotune.enable(True)
+    try:
+        first = main(parse(argv + dirs("a")))
+        autotune.save(plans)
+    finally:
+        autotune.enable(False)
+        autotune.reset()
+    rows = json.load(open(plans))
+    assert rows, "the tuner saw no layer shape"
+    second = main(parse(argv + dirs("b") + ["--contraction_plans", plans]))
+    try:
+        for k in first:
+            if getattr(first[k], "numel", lambda: 0)() == 1:
+                assert float(first[k]) == float(second[k]), k
+        for row in rows:
+            g = L.ConvGeom(*row["geom"])
+            for mode, (cfg, splits, _, _) in row["plans"].items():
+                c, s, thin = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                L.check(L.lib.gan_conv_plan_get(int(mode), ctypes.byref(g), ctypes.byref(c), ctypes.byref(s), ctypes.byref(thin)))
+                # (the planner may round a split count down to what the k range divides into)
+                assert thin.value or (c.value == cfg and 0 < s.value <= splits), (row["geom"], mode)
+    finally:
+        autotune.reset()
+
+
+@pytest.mark.gpu
 def test_undefined_and_out_of_scope_models_raise(tmp_path):
     from gan_amd.main import main
     common = ["--checkpoint_dir", str(tmp_path / "c"), "--sample_dir", str(tmp_path / "s")]
